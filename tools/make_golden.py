@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by IMPORTING the reference in the build container.
+
+Runs only where /root/reference exists (never on the GPU box, never from tests/).  It installs four
+empty stub modules for dependencies that are absent offline (cv2, torchvision, ellipse, argus), imports the
+reference's own modules read-only, feeds them build-owned deterministic inputs (oracle/synth.py,
+oracle/hrnet_ref.py::seeded_*), and stores small arrays of inputs -> expected outputs.  Nothing from
+the reference's source text is stored: fixtures are data.
+
+While it runs it also asserts that the oracle/ restatements agree with the imported reference, i.e.
+it is the "pin" of the oracle.  Usage:  python tools/make_golden.py
+"""
+import io
+import json
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    cv2 = types.ModuleType('cv2')
+    cv2.RANSAC = 8
+
+    def _nocv(*a, **k):
+        raise RuntimeError('cv2 is not available offline')
+    for n in ('findHomography', 'calibrateCamera', 'Rodrigues', 'solvePnPRansac', 'solvePnPRefineLM'):
+        setattr(cv2, n, _nocv)
+    sys.modules['cv2'] = cv2
+    tv = types.ModuleType('torchvision')
+    tvt = types.ModuleType('torchvision.transforms')
+    tvt.ToTensor = object
+    tv.transforms = tvt
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.transforms'] = tvt
+    ar = types.ModuleType('argus')
+    ar.load_model = None
+    ar.Model = type('Model', (), {'__init__': lambda self, params=None: None})
+    are = types.ModuleType('argus.engine'); are.State = object
+    aru = types.ModuleType('argus.utils'); aru.deep_detach = aru.deep_to = None
+    ar.engine, ar.utils = are, aru
+    sys.modules.update({'argus': ar, 'argus.engine': are, 'argus.utils': aru})
+    el = types.ModuleType('ellipse')
+    el.LsqEllipse = object
+    sys.modules['ellipse'] = el
+    sys.path.insert(0, REF)
+
+
+class AttrDict(dict):
+    """dict with attribute access AND `in` (hrnet.py:306,314 uses both)."""
+    def __getattr__(self, k):
+        v = self[k]
+        return AttrDict(v) if isinstance(v, dict) else v
+
+
+def ref_cfg(cfg):
+    c = {k: v for k, v in cfg.items() if k not in ('head',)}
+    if c.get('upscale', 1) == 1:
+        c.pop('upscale', None)
+    return AttrDict(c)
+
+
+def checksum(a: np.ndarray) -> float:
+    return float(np.sum(a.astype(np.float64)))
+
+
+def gen_pitch():
+    from src.datatools.ellipse import PITCH_POINTS, INTERSECTON_TO_PITCH_POINTS
+    from src.models.hrnet import prediction as rp
+    from src.datatools.line import LINE_CLS
+    from src.datatools.intersections import LINE_INTERSECTIONS
+    from oracle import pitch as op, lines as ol
+    P = np.stack([PITCH_POINTS[INTERSECTON_TO_PITCH_POINTS[i]] for i in range(57)])
+    assert np.abs(P - op.pitch_points()).max() < 1e-12, np.abs(P - op.pitch_points()).max()
+    assert rp.top_gates == op.TOP_GATES and rp.keep_points == op.KEEP_POINTS
+    assert [i for i in rp.point_sets['groundplane'] if i < 57] == op.GROUND
+    assert rp.point_sets['goal_left'] == op.GOAL_LEFT and rp.point_sets['goal_right'] == op.GOAL_RIGHT
+    assert [LINE_CLS[i] for i in range(23)] == ol.LINE_CLS
+    assert {k: tuple(v) for k, v in LINE_INTERSECTIONS.items()} == ol.LINE_INTERSECTIONS
+    np.savez(os.path.join(GOLD, 'pitch.npz'), points=P,
+             names=np.array([INTERSECTON_TO_PITCH_POINTS[i] for i in range(57)]),
+             keep_points=np.array(rp.keep_points), goal_left=np.array(rp.point_sets['goal_left']),
+             goal_right=np.array(rp.point_sets['goal_right']), top_gates=np.array(rp.top_gates),
+             line_cls=np.array([LINE_CLS[i] for i in range(23)]),
+             line_pairs=np.array([list(LINE_INTERSECTIONS[i]) for i in range(30)]))
+    print('pitch ok')
+
+
+def tie_suite(h, w):
+    """Engineered (1,58,h,w) log-heatmap exercising the separable first-occurrence tie rule (H1)."""
+    lp = np.full((1, 58, h, w), -20.0, dtype=np.float32)
+    lp[0, 0, 10, w - 20] = -0.5; lp[0, 0, h - 5, 7] = -0.5        # equal maxima: x from col 7, y from row 10
+    lp[0, 1] = -3.0                                              # all-equal channel -> (0,0)
+    lp[0, 2, 3, 5] = -1e-9; lp[0, 2, 2, 9] = -2e-9               # distinct logp that collide at exp()==1.0
+    lp[0, 3, h - 1, w - 1] = -0.1                                # last pixel
+    lp[0, 4, 0, 0] = -0.25
+    lp[0, 5, 5, 5] = -np.inf; lp[0, 5, 6, 6] = -1.0              # -inf is legal input
+    lp[0, 6, :, 11] = -0.7                                       # a whole column of equal maxima
+    lp[0, 7, 13, :] = -0.7                                       # a whole row of equal maxima
+    lp[0, 8, 4, 4] = np.float32(-1.0); lp[0, 8, 3, 8] = np.nextafter(np.float32(-1.0), np.float32(0))
+    return lp
+
+
+def gen_decode():
+    from src.models.hrnet.transforms import HRNetPredictionTransform
+    from src.models.line.transforms import EHMPredictionTransform
+    from oracle import decode as od, synth
+    out = {}
+    cases = []
+    lp, kps = synth.synth_logp(list(range(4)), hw=(68, 120))
+    cases.append(('gauss_68x120', lp))
+    lp, _ = synth.synth_logp([7, 8], hw=(135, 240), floor=0)      # exact zeros -> -inf
+    cases.append(('gauss_135x240_neginf', lp))
+    cases.append(('ties_34x60', tie_suite(34, 60)))
+    rng = np.random.Generator(np.random.PCG64(5))
+    noise = torch.log_softmax(torch.from_numpy((rng.random((2, 58, 34, 60)) * 8).astype(np.float32)), 1).numpy()
+    cases.append(('noise_34x60', noise))
+    tr = HRNetPredictionTransform((540, 960))
+    for name, lp in cases:
+        ref = tr(torch.from_numpy(lp)).numpy()
+        mine = od.keypoint_decode(lp, (540, 960))
+        assert np.array_equal(ref[..., :2], mine[..., :2]), name
+        assert np.allclose(ref[..., 2], mine[..., 2], rtol=2e-7, atol=0), name
+        out[name + '.in'] = lp if lp.size < 300000 else np.zeros(0, np.float32)
+        out[name + '.out'] = ref
+    out['seeds.gauss_68x120'] = np.arange(4)
+    out['seeds.gauss_135x240_neginf'] = np.array([7, 8])
+    np.savez_compressed(os.path.join(GOLD, 'decode_keypoints.npz'), **out)
+    # line decode
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, C, H, W = 2, 23, 34, 60
+    heat = np.zeros((B, C, H, W), dtype=np.float32)
+    for b in range(B):
+        for c in range(C):
+            for _ in range(2):
+                x0, y0 = rng.uniform(0, W), rng.uniform(0, H)
+                amp = rng.uniform(0.1, 1.0)
+                xs = np.arange(W)[None, :]; ys = np.arange(H)[:, None]
+                heat[b, c] += (amp * np.exp(-((xs - x0) ** 2 + (ys - y0) ** 2) / (2 * 1.5 ** 2))).astype(np.float32)
+    heat -= 0.02
+    heat[0, 3] = 0.0                       # empty channel
+    heat[1, 5] = -1.0                      # all negative -> relu -> zeros
+    for sigma, scale in ((3.0, 4.0), (6.0, 4.0)):
+        ref = EHMPredictionTransform(scale=scale, sigma=sigma)(torch.from_numpy(heat.copy())).numpy()
+        mine = od.line_decode(heat, sigma, scale)
+        assert np.array_equal(ref[..., :2], mine[..., :2]), (sigma, np.abs(ref - mine).max())
+        assert np.allclose(ref[..., 2], mine[..., 2], rtol=1e-5, atol=1e-7)
+        out[f'out_sigma{int(sigma)}'] = ref
+    out['heat'] = heat
+    np.savez_compressed(os.path.join(GOLD, 'decode_lines.npz'), **out)
+    print('decode ok')
+
+
+def gen_camera():
+    from baseline.camera import Camera
+    from src.models.hrnet.prediction import good_camera
+    from oracle import camera_math as cm, synth, pitch as op
+    P = op.pitch_points()
+    recs = []
+    for seed in range(8):
+        rng = np.random.Generator(np.random.PCG64(100 + seed))
+        cam = synth.sample_camera(rng)
+        c = Camera(960, 540)
+        c.position = cam['position'].copy(); c.rotation = cam['rotation'].copy()
+        c.xfocal_length = c.yfocal_length = cam['f']
+        c.calibration = np.array([[cam['f'], 0, 480.], [0, cam['f'], 270.], [0, 0, 1.]])
+        proj = np.stack([c.project_point(p) for p in P])
+        mine = np.stack([cm.project_point(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.), p) for p in P])
+        assert np.abs(proj - mine).max() < 1e-9
+        js = c.to_json_parameters()
+        mj = cm.to_json(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.))
+        for k in ('pan_degrees', 'tilt_degrees', 'roll_degrees'):
+            assert abs(js[k] - mj[k]) < 1e-10
+        c2 = Camera(960, 540); c2.from_json_parameters(js)
+        assert np.abs(c2.rotation - cm.rotation_from_ptr(*np.deg2rad([js['pan_degrees'], js['tilt_degrees'], js['roll_degrees']]))).max() < 1e-12
+        vis = proj[:, 2] > 0
+        obs = proj[vis, :2] + rng.normal(0, 1.5, (int(vis.sum()), 2))
+        mp = [(P[i], tuple(obs[k])) for k, i in enumerate(np.nonzero(vis)[0])]
+        rm = c.projection_rmse(mp)
+        assert abs(rm - cm.projection_rmse(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.), P[vis], obs)) < 1e-9
+        # plane homography world(z=0) -> image and K-from-H
+        K = c.calibration; R = c.rotation; t = -R @ c.position
+        Hm = K @ np.column_stack([R[:, 0], R[:, 1], t]); Hm /= Hm[2, 2]
+        ch = Camera(960, 540)
+        ok, Kest = ch.estimate_calibration_matrix_from_plane_homography(Hm)
+        ok2, fx2, fy2 = cm.k_from_plane_homography(Hm)
+        assert ok == ok2 and (not ok or (abs(Kest[0, 0] - fx2) < 1e-6 * fx2 and abs(Kest[1, 1] - fy2) < 1e-6 * fy2))
+        ch2 = Camera(960, 540); okh = ch2.from_homography(Hm)
+        recs.append(dict(position=cam['position'], rotation=cam['rotation'], f=cam['f'], proj=proj,
+                         json=js, rot_from_json=c2.rotation, obs_ids=np.nonzero(vis)[0], obs=obs, rmse=rm,
+                         H=Hm, k_ok=ok, k_fx=Kest[0, 0], k_fy=Kest[1, 1], fh_ok=bool(okh),
+                         fh_rot=ch2.rotation, fh_pos=ch2.position, fh_fx=ch2.xfocal_length,
+                         good=bool(good_camera(c.calibration, c.position))))
+    flat = {}
+    for i, r in enumerate(recs):
+        for k, v in r.items():
+            flat[f'{i}.{k}'] = json.dumps(v) if isinstance(v, dict) else np.asarray(v)
+    flat['n'] = np.array(len(recs))
+    np.savez(os.path.join(GOLD, 'camera.npz'), **flat)
+    print('camera ok')
+
+
+def gen_lines():
+    from src.utils.export_line_result import get_line_data, calculate_slope_intercept
+    from src.models.hrnet.prediction import line_eq_intersection, CameraCreator
+    from src.datatools.ellipse import PITCH_POINTS
+    from oracle import lines as ol
+    import pickle
+    import tempfile
+    g = np.load(os.path.join(GOLD, 'decode_lines.npz'))
+    hl = g['out_sigma3'][:1] / np.array([4, 4, 1], dtype=np.float32)   # back to heatmap units
+    lines, points = get_line_data(hl, scale=4, prob_thre=0.2)
+    ml, mp = ol.get_line_data(hl, scale=4, prob_thre=0.2)
+    assert lines.keys() == ml.keys()
+    for k in lines:
+        assert np.allclose(lines[k], ml[k])
+    assert calculate_slope_intercept((1., 2.), (1., 2.)) == ol.slope_intercept((1., 2.), (1., 2.)) == (None, None)
+    # ingestion through CameraCreator.__init__ (prediction.py:105-124)
+    pk = {'img_a.jpg': {'lines': [dict(lines)], 'points': [points]}}
+    pk['img_a.jpg']['lines'][0]['Goal left post left'] = (0.3, 11.0)     # key without trailing blank
+    pk['img_a.jpg']['lines'][0].pop('Goal left post left ', None)
+    with tempfile.NamedTemporaryFile(suffix='.pkl', delete=False) as f:
+        pickle.dump(pk, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc = CameraCreator(PITCH_POINTS, lines_file=f.name)
+    os.unlink(f.name)
+    got = cc.lines_data.get('img_a.jpg', {})
+    mine = ol.lines_to_keypoints(pk['img_a.jpg']['lines'][0])
+    assert got.keys() == mine.keys() and all(np.allclose(got[k], mine[k]) for k in got)
+    assert line_eq_intersection((1.0, 0.0), (1.00001, 5.0)) is None
+    rec = {'lines': {k: [float(v[0]), float(v[1])] for k, v in pk['img_a.jpg']['lines'][0].items()},
+           'keypoints': {str(k): [float(v[0]), float(v[1])] for k, v in got.items()},
+           'points': {k: [[float(x) for x in p] for p in v] for k, v in points.items()}}
+    with open(os.path.join(GOLD, 'lines.json'), 'w') as f:
+        json.dump(rec, f, indent=1)
+    print('lines ok', len(got), 'intersections')
+
+
+def gen_evaluator():
+    """H2: get_polylines / evaluate_camera_prediction on the Camera JSON contract (numpy only)."""
+    from baseline.evaluate_camera import get_polylines, evaluate_camera_prediction
+    from oracle import synth, camera_math as cm
+    recs = {}
+    for seed in range(3):
+        rng = np.random.Generator(np.random.PCG64(200 + seed))
+        cam = synth.sample_camera(rng)
+        js = cm.to_json(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.))
+        poly = get_polylines(js, 960, 540, sampling_factor=0.9)
+        # perturbed camera as "prediction"
+        cam2 = dict(cam); cam2['position'] = cam['position'] + np.array([0.3, -0.2, 0.1])
+        js2 = cm.to_json(cam2['position'], cam2['rotation'], cam2['f'] * 1.01, cam2['f'] * 1.01, (480., 270.))
+        poly2 = get_polylines(js2, 960, 540, sampling_factor=0.9)
+        gt = {k: [v[0], v[-1]] for k, v in poly.items()}
+        conf, _, errs = evaluate_camera_prediction(poly2, gt, 5)
+        recs[str(seed)] = {'json': js, 'pred_json': js2,
+                           'n_classes': len(poly), 'npts': {k: len(v) for k, v in poly.items()},
+                           'first': {k: [v[0]['x'], v[0]['y']] for k, v in poly.items()},
+                           'confusion': conf.tolist(),
+                           'mean_err': {k: float(np.mean(v)) for k, v in errs.items()}}
+    with open(os.path.join(GOLD, 'evaluator.json'), 'w') as f:
+        json.dump(recs, f, indent=1)
+    print('evaluator ok')
+
+
+def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, batch=1):
+    from oracle import hrnet_ref as hr, decode as od
+    cfg = hr.load_config(cfg_name)
+    if line:
+        from src.models.line.model import HRNetHeatmap
+    else:
+        from src.models.hrnet.model import HRNetHeatmap
+    torch.manual_seed(0)
+    net = HRNetHeatmap(ref_cfg(cfg), num_refinement_stages=0, num_heatmaps=cfg['num_classes'])
+    sd = hr.seeded_state_dict(cfg, seed, head_gain)
+    missing = net.load_state_dict(sd, strict=True)       # validates names + shapes of the enumerator
+    net.eval()
+    x = hr.seeded_input(batch, hw[0], hw[1], seed + 1)
+    with torch.no_grad():
+        ref = net(x)[-1]
+    mine, inter = hr.forward(sd, x, cfg, return_intermediates=True)
+    err = (ref - mine).abs().max().item()
+    assert err < 1e-4, err
+    refn = ref.numpy()
+    out = {'hw': np.array(hw), 'seed': np.array(seed), 'head_gain': np.array(head_gain), 'batch': np.array(batch),
+           'checksum': np.array(checksum(refn)), 'abs_checksum': np.array(checksum(np.abs(refn))),
+           'n_params': np.array(sum(int(v.numel()) for k, v in sd.items() if 'num_batches' not in k)),
+           'macs': np.array(hr.conv_macs(cfg, hw[0], hw[1]))}
+    if line:
+        tr_out = od.line_decode(refn, 3.0, 4.0)
+        from src.models.line.transforms import EHMPredictionTransform
+        ref_dec = EHMPredictionTransform(scale=4, sigma=3)(ref.clone()).numpy()
+        assert np.array_equal(ref_dec[..., :2], tr_out[..., :2])
+        out['decode'] = ref_dec
+        out['maxp'] = refn.max(axis=(2, 3))
+    else:
+        from src.models.hrnet.transforms import HRNetPredictionTransform
+        ref_dec = HRNetPredictionTransform((540, 960))(ref).numpy()
+        assert np.array_equal(ref_dec[..., :2], od.keypoint_decode(refn, (540, 960))[..., :2])
+        out['decode'] = ref_dec
+        p = np.exp(refn)
+        flat = np.sort(p.reshape(p.shape[0], p.shape[1], -1), axis=-1)
+        out['maxp'] = flat[..., -1]
+        out['gap'] = (flat[..., -1] - flat[..., -2])          # top-1 / top-2 separation per channel
+    if store_full:
+        out['out'] = refn
+    else:
+        out['out_strided'] = refn[:, :, ::16, ::16].copy()
+    for k in ('stage2', 'stage3', 'stage4'):
+        for bi, t in enumerate(inter[k]):
+            out[f'{k}.{bi}.checksum'] = np.array(checksum(t.numpy()))
+            out[f'{k}.{bi}.abs'] = np.array(checksum(np.abs(t.numpy())))
+            if store_full:
+                out[f'{k}.{bi}'] = t.numpy()[:, ::4].copy()      # every 4th channel keeps it small
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    print(name, 'ok: max|ref-oracle| =', err, 'params', int(out['n_params']), 'GMAC', int(out['macs']) / 1e9,
+          'maxp range', float(out['maxp'].min()), float(out['maxp'].max()),
+          ('min gap %.3g' % float(out['gap'].min())) if 'gap' in out else '')
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    install_stubs()
+    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'hrnet']
+    if 'pitch' in which:
+        gen_pitch()
+    if 'decode' in which:
+        gen_decode()
+    if 'camera' in which:
+        gen_camera()
+    if 'lines' in which:
+        gen_lines()
+    if 'evaluator' in which:
+        gen_evaluator()
+    if 'hrnet' in which:
+        gen_hrnet('hrnet_w18_64x96', 'hrnet_w18', (64, 96), 3, 4.0)
+        gen_hrnet('hrnet_w18_135x240', 'hrnet_w18', (135, 240), 5, 4.0, store_full=False, batch=2)
+        gen_hrnet('line_w18_64x96', 'line_hrnet_w18', (64, 96), 4, 4.0, line=True)
+        gen_hrnet('hrnet_w48_540x960', 'hrnet_w48', (540, 960), 1, 1.5, store_full=False)
+        gen_hrnet('line_w48_540x960', 'line_hrnet_w48', (540, 960), 2, 1.5, line=True, store_full=False)

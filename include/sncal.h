@@ -1,0 +1,173 @@
+/*
+ * sncal.h -- C ABI of libsncal.so: the MI355X (gfx950) implementation of the per-frame camera
+ * calibration hot path of NikolasEnt/soccernet-calibration-sportlight.
+ *
+ * The reference has no FFI: the path sits behind three Python call surfaces.  Each
+ * entry point below names the reference interface it replaces (file:line under /root/reference);
+ * the Python host mirror (the .py files of soccernet-calibration-sportlight_amd) binds them with ctypes and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative sncal_status; the message of the last
+ *     failure on the calling thread is available from sncal_last_error();
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); nothing synchronises
+ *     the stream or the device unless stated;
+ *   - pointers named d_* are DEVICE pointers, h_* are HOST pointers; the library never allocates
+ *     behind the caller's back on the data path: scratch comes from caller-provided workspaces
+ *     whose size is returned by the matching *_workspace() query;
+ *   - no torch / C++ types cross the boundary: plain pointers, ints, floats, doubles.
+ */
+#ifndef SNCAL_H
+#define SNCAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNCAL_VERSION 100
+
+typedef enum {
+    SNCAL_OK = 0,
+    SNCAL_ERR_ARG = -1,        /* invalid argument (shape, null pointer, unsupported size)  */
+    SNCAL_ERR_HIP = -2,        /* a HIP runtime call or kernel launch failed                */
+    SNCAL_ERR_STATE = -3,      /* object not finalised / weights missing                    */
+    SNCAL_ERR_WORKSPACE = -4   /* caller workspace too small                                */
+} sncal_status;
+
+typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1 } sncal_dtype;
+
+int sncal_version(void);
+const char* sncal_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * D1  keypoint heatmap decode
+ * replaces HRNetPredictionTransform.__call__  src/models/hrnet/transforms.py:228-239
+ *   d_logp  (B,C,h,w) fp32 log-probabilities, NCHW contiguous
+ *   d_out   (B,C-1,3) fp32 rows [x_px, y_px, conf]; the last (background) channel is dropped
+ *   x = first column holding the channel maximum of exp(logp), y = first row holding it (the two
+ *   come from separate reductions, exactly like the reference), conf = that maximum,
+ *   x_px = x*img_w/w, y_px = y*img_h/h.   exp is float32(exp(float64(.))) -- see oracle/decode.py.
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_heatmap_decode(const float* d_logp, int B, int C, int h, int w, int img_h, int img_w,
+                         float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L2  line heatmap 2-peak decode
+ * replaces EHMPredictionTransform.__call__ / mask_heat_points_gauss
+ *          src/models/line/transforms.py:217-280
+ *   d_heat (B,C,h,w) fp32;  d_out (B,C,2,3) fp32 rows [x*scale, y*scale, value]
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_line_decode(const float* d_heat, int B, int C, int h, int w, float sigma, float scale,
+                      float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * M1-M5, L1  HRNet keypoint / line network
+ * replaces HighResolutionNet.__init__/forward  src/models/hrnet/hrnet.py:255-355, 437-511,
+ *          src/models/line/hrnet.py:30-249, HRNetHeatmap.forward src/models/hrnet/model.py:143-150
+ * The descriptor carries the fields of the reference's model_config yaml
+ * (src/models/hrnet/model_config/hrnet_w48.yaml).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int num_classes;            /* 58 keypoint net, 23 line net                                  */
+    int stem_width;             /* 64                                                            */
+    int upscale;                /* 2: bilinear x2 of all branches + stem concat; 1: line net     */
+    int head_softmax;           /* 0 = LogSoftmax(dim=1) head, 1 = Softmax(dim=1) head           */
+    int stage1_blocks;          /* number of Bottleneck blocks in layer1                         */
+    int stage1_channels;        /* Bottleneck planes (output = 4x)                               */
+    int num_modules[3];         /* stage2..4                                                     */
+    int num_branches[3];        /* 2,3,4                                                         */
+    int num_blocks[3];          /* BasicBlocks per branch (uniform per stage in every config)    */
+    int num_channels[3][4];     /* branch widths per stage                                       */
+} sncal_hrnet_desc;
+
+typedef struct sncal_hrnet sncal_hrnet;
+
+/* Build the execution plan (no weights yet).  dtype selects the arithmetic of the conv kernels:
+ * SNCAL_BF16 = bf16 activations/weights with fp32 MFMA accumulation (fast path),
+ * SNCAL_F32  = fp32 activations/weights on the exact-fp32 MFMA (parity path). */
+int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out);
+void sncal_hrnet_destroy(sncal_hrnet* net);
+
+/* The plan's conv units in the reference's registration order, with the state-dict prefixes the
+ * host needs to fetch weights ("model.stage3.2.branches.1.0.conv1" / "...bn1"). */
+int sncal_hrnet_num_convs(const sncal_hrnet* net);
+int sncal_hrnet_conv_info(const sncal_hrnet* net, int idx, char* name, int name_cap, char* bn_name,
+                          int bn_cap, int* cin, int* cout, int* ksize, int* stride, int* has_bias);
+/* Give conv `idx` its weights: h_weight (Cout,Cin,k,k) fp32 host, h_scale/h_shift (Cout) fp32 host
+ * = the eval-mode BatchNorm folded to y = conv(x)*scale + shift (scale NULL => 1). */
+int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_weight, const float* h_scale,
+                         const float* h_shift);
+/* Pack + upload all weights (synchronous).  Every conv must have been set. */
+int sncal_hrnet_finalize(sncal_hrnet* net);
+
+/* Output spatial size and workspace bytes for a (B,3,H,W) input. */
+int sncal_hrnet_output_size(const sncal_hrnet* net, int H, int W, int* out_h, int* out_w);
+int sncal_hrnet_workspace(const sncal_hrnet* net, int B, int H, int W, size_t* bytes);
+
+/* Forward.  d_x (B,3,H,W) fp32 NCHW in [0,1] (what make_submit.py:66-67 builds).
+ *   d_heat  optional (B,num_classes,h,w) fp32 NCHW head output (log-softmax / softmax)
+ *   d_kpts  optional (B,num_classes-1,3) fp32 decoded keypoints (keypoint net only; D1 semantics
+ *           with size = (img_h,img_w))
+ * At least one of d_heat / d_kpts must be non-NULL. */
+int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat,
+                        float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * S0-S11  camera solve (batched, one wavefront per frame)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {              /* one solved camera; mirrors baseline/camera.py:79-90 attributes     */
+    double position[3];
+    double rotation[9];       /* row-major R, X_cam = R (X_world - position)                       */
+    double fx, fy;            /* calibration[0,0], calibration[1,1]                                */
+    double cx, cy;            /* calibration[0,2], [1,2] used by solve_pnp/refine (Q3)             */
+    double rmse;              /* Camera.projection_rmse of the selected camera (mean L2, px)       */
+    int32_t status;           /* 0 = no camera (reference returns None), >0 = which branch produced it */
+    int32_t n_points;         /* matched points used                                               */
+} sncal_camera;
+
+enum {                        /* sncal_camera.status                                               */
+    SNCAL_CAM_NONE = 0,
+    SNCAL_CAM_ORIGINAL = 1,       /* original_voter calibrate path  prediction.py:396-433          */
+    SNCAL_CAM_ORIGINAL_HOM = 2,   /* original_voter homography fallback  :434-436                  */
+    SNCAL_CAM_VOTER_REL = 3, SNCAL_CAM_VOTER_ACC = 4, SNCAL_CAM_VOTER_ALL = 5,
+    SNCAL_CAM_VOTER_GROUND = 6,   /* voter winners  :293-323                                       */
+    SNCAL_CAM_VOTER_HOM = 7       /* voter homography fallback  :327-329                           */
+};
+
+typedef struct {              /* CameraCreator kwargs, make_submit.py:45-50                        */
+    int algorithm;            /* 0 iterative_voter, 1 original_voter, 2 voter,
+                                 3 opencv_calibration, 4 opencv_calibration_multiplane            */
+    float conf_thresh;
+    float conf_threshs[4];
+    int n_conf_threshs;
+    double max_rmse, max_rmse_rel;
+    int min_points, min_points_per_plane, min_points_for_refinement, reliable_thresh;
+    double min_focal_length;
+    int img_w, img_h;
+} sncal_voter_cfg;
+
+/* Camera.refine_camera  baseline/camera.py:105-119 (cv.solvePnPRefineLM, K fixed, 6-DoF pose LM).
+ *   d_K (B,4) fx,fy,cx,cy   d_pts3d (B,N,3) fp64   d_pts2d (B,N,2) fp64   d_npts (B) int32
+ *   d_rt (B,12) in/out: rotation row-major (9) + position (3)   d_rmse (B) out mean-L2 px */
+int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d,
+                        const int32_t* d_npts, int B, int N, double* d_rt, double* d_rmse,
+                        int max_iters, double eps, void* stream);
+
+/* Camera.solve_pnp  baseline/camera.py:92-103 (cv.solvePnPRansac + Rodrigues), same layouts. */
+int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pts2d,
+                    const int32_t* d_npts, int B, int N, double* d_rt, void* stream);
+
+/* CameraCreator.__call__  src/models/hrnet/prediction.py:130-136 with every algorithm of :90-96.
+ *   d_kpts (B,57,3) fp32 decoded keypoints   d_line_pts (B,30,3) fp32 [x,y,valid] or NULL
+ *   d_out (B) sncal_camera.  Never fails per frame: status 0 == the reference's `None`. */
+int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                    sncal_camera* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNCAL_H */

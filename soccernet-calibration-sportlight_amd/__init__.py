@@ -1,0 +1,9 @@
+"""MI355X-native per-frame soccer camera calibration hot path (HRNet heatmaps -> decode -> camera solve).
+
+Host mirror of the reference's Python call surfaces over libsncal.so (HIP, gfx950).
+Import as ``import sncal_amd`` (alias module at the repo root) -- the directory name carries a hyphen.
+"""
+from . import _lib  # noqa: F401
+from .transforms import HRNetPredictionTransform, EHMPredictionTransform  # noqa: F401
+
+__all__ = ['HRNetPredictionTransform', 'EHMPredictionTransform']

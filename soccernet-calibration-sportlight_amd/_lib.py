@@ -1,0 +1,119 @@
+"""ctypes binding of libsncal.so (the C ABI declared in include/sncal.h).
+
+There is NO fallback: if the library is missing or a symbol cannot be resolved, importing the product
+path raises.  PyTorch is used by the callers only for device memory and streams.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libsncal.so')
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+
+
+class HRNetDesc(ctypes.Structure):
+    """sncal_hrnet_desc."""
+    _fields_ = [('num_classes', ctypes.c_int), ('stem_width', ctypes.c_int), ('upscale', ctypes.c_int),
+                ('head_softmax', ctypes.c_int), ('stage1_blocks', ctypes.c_int),
+                ('stage1_channels', ctypes.c_int), ('num_modules', ctypes.c_int * 3),
+                ('num_branches', ctypes.c_int * 3), ('num_blocks', ctypes.c_int * 3),
+                ('num_channels', (ctypes.c_int * 4) * 3)]
+
+
+class Camera(ctypes.Structure):
+    """sncal_camera."""
+    _fields_ = [('position', ctypes.c_double * 3), ('rotation', ctypes.c_double * 9),
+                ('fx', ctypes.c_double), ('fy', ctypes.c_double), ('cx', ctypes.c_double),
+                ('cy', ctypes.c_double), ('rmse', ctypes.c_double), ('status', ctypes.c_int32),
+                ('n_points', ctypes.c_int32)]
+
+
+class VoterCfg(ctypes.Structure):
+    """sncal_voter_cfg."""
+    _fields_ = [('algorithm', ctypes.c_int), ('conf_thresh', ctypes.c_float),
+                ('conf_threshs', ctypes.c_float * 4), ('n_conf_threshs', ctypes.c_int),
+                ('max_rmse', ctypes.c_double), ('max_rmse_rel', ctypes.c_double),
+                ('min_points', ctypes.c_int), ('min_points_per_plane', ctypes.c_int),
+                ('min_points_for_refinement', ctypes.c_int), ('reliable_thresh', ctypes.c_int),
+                ('min_focal_length', ctypes.c_double), ('img_w', ctypes.c_int), ('img_h', ctypes.c_int)]
+
+
+# name -> (restype, argtypes); must list every function include/sncal.h declares
+SIGNATURES = {
+    'sncal_version': (ctypes.c_int, []),
+    'sncal_last_error': (ctypes.c_char_p, []),
+    'sncal_heatmap_decode': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, vp, vp]),
+    'sncal_line_decode': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_float, ctypes.c_float, vp, vp]),
+    'sncal_hrnet_create': (ctypes.c_int, [ctypes.POINTER(HRNetDesc), ctypes.c_int, ctypes.POINTER(vp)]),
+    'sncal_hrnet_destroy': (None, [vp]),
+    'sncal_hrnet_num_convs': (ctypes.c_int, [vp]),
+    'sncal_hrnet_conv_info': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p,
+                                             ctypes.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    'sncal_hrnet_set_conv': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
+    'sncal_hrnet_finalize': (ctypes.c_int, [vp]),
+    'sncal_hrnet_output_size': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
+    'sncal_hrnet_workspace': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_size_t)]),
+    'sncal_hrnet_forward': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
+                                           ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    'sncal_pnp_refine_lm': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
+                                           ctypes.c_double, vp]),
+    'sncal_solve_pnp': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    'sncal_calibrate': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp]),
+}
+
+_lib = None
+MISSING = []
+
+
+class SncalError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsncal.so once; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SncalError(f'{LIB_PATH} is missing: build it with __graft_entry__.build() '
+                             '(hipcc --offload-arch=gfx950); this package has no CPU fallback')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:          # calling it later raises; tests/test_abi.py requires none
+                MISSING.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = lib().sncal_last_error().decode(errors='replace')
+        raise SncalError(f'{what} failed with status {status}: {msg}')
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream as an integer (0 = default stream)."""
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t, dtype, name):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SncalError(f'{name} must be a tensor on the GPU (libsncal has no CPU path)')
+    if t.dtype != dtype:
+        raise SncalError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise SncalError(f'{name} must be contiguous')
+    return t

@@ -1,0 +1,16 @@
+// libsncal.so: version + thread-local error string.
+#include "common.hpp"
+#include <cstring>
+
+namespace sncal {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace sncal
+
+extern "C" int sncal_version(void) { return SNCAL_VERSION; }
+extern "C" const char* sncal_last_error(void) { return sncal::g_err; }

@@ -1,0 +1,95 @@
+"""CPU: the oracle/ restatements against the golden vectors captured from the imported reference
+(tools/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import camera_math as cm
+from oracle import decode as od
+from oracle import lines as ol
+from oracle import pitch as op
+from oracle import synth
+
+
+GAUSS_CASES = {'gauss_68x120': ((68, 120), 1e-12), 'gauss_135x240_neginf': ((135, 240), 0)}
+
+
+def regen_gauss_case(g, case):
+    hw, floor = GAUSS_CASES[case]
+    return synth.synth_logp(list(g['seeds.' + case]), hw=hw, floor=floor)[0]
+
+
+def test_pitch_template(gold_dir):
+    g = np.load(os.path.join(gold_dir, 'pitch.npz'))
+    assert np.abs(g['points'] - op.pitch_points()).max() < 1e-12
+    assert list(g['keep_points']) == op.KEEP_POINTS and 29 not in op.KEEP_POINTS   # Q7
+    assert list(g['goal_left']) == op.GOAL_LEFT and list(g['goal_right']) == op.GOAL_RIGHT
+    assert list(g['top_gates']) == op.TOP_GATES
+    assert list(g['line_cls']) == ol.LINE_CLS
+    assert [tuple(p) for p in g['line_pairs']] == [ol.LINE_INTERSECTIONS[i] for i in range(30)]
+
+
+@pytest.mark.parametrize('case', ['gauss_68x120', 'gauss_135x240_neginf', 'ties_34x60', 'noise_34x60'])
+def test_keypoint_decode_golden(gold_dir, case):
+    g = np.load(os.path.join(gold_dir, 'decode_keypoints.npz'))
+    lp = g[case + '.in']
+    if lp.size == 0:   # large inputs are regenerated from their seeds
+        lp = regen_gauss_case(g, case)
+    out = od.keypoint_decode(lp, (540, 960))
+    ref = g[case + '.out']
+    assert np.array_equal(out[..., :2], ref[..., :2])            # indices: bit-identical
+    assert np.allclose(out[..., 2], ref[..., 2], rtol=2e-7, atol=0)   # conf: 1 ULP (exp implementation)
+
+
+def test_tie_rule_is_separable(gold_dir):
+    """H1: x and y come from separate reductions and need not belong to one pixel."""
+    g = np.load(os.path.join(gold_dir, 'decode_keypoints.npz'))
+    out = g['ties_34x60.out'][0]
+    assert tuple(out[0, :2]) == (7 * 960 / 60, 10 * 540 / 34)     # col of one maximum, row of the other
+    assert tuple(out[1, :2]) == (0.0, 0.0)                         # all-equal channel
+    assert tuple(out[2, :2]) == (5 * 16.0, np.float32(2 * 540) / np.float32(34))   # exp() collision at 1.0
+
+
+@pytest.mark.parametrize('sigma', [3, 6])
+def test_line_decode_golden(gold_dir, sigma):
+    g = np.load(os.path.join(gold_dir, 'decode_lines.npz'))
+    out = od.line_decode(g['heat'], float(sigma), 4.0)
+    ref = g[f'out_sigma{sigma}']
+    assert np.array_equal(out[..., :2], ref[..., :2])
+    assert np.allclose(out[..., 2], ref[..., 2], rtol=1e-5, atol=1e-7)
+
+
+def test_camera_math_golden(gold_dir):
+    g = np.load(os.path.join(gold_dir, 'camera.npz'), allow_pickle=False)
+    P = op.pitch_points()
+    for i in range(int(g['n'])):
+        pos, R, f = g[f'{i}.position'], g[f'{i}.rotation'], float(g[f'{i}.f'])
+        proj = np.stack([cm.project_point(pos, R, f, f, (480., 270.), p) for p in P])
+        assert np.abs(proj - g[f'{i}.proj']).max() < 1e-9
+        js = json.loads(str(g[f'{i}.json']))
+        mine = cm.to_json(pos, R, f, f, (480., 270.))
+        for k in ('pan_degrees', 'tilt_degrees', 'roll_degrees'):
+            assert abs(js[k] - mine[k]) < 1e-10
+        Rj = cm.rotation_from_ptr(*np.deg2rad([js['pan_degrees'], js['tilt_degrees'], js['roll_degrees']]))
+        assert np.abs(Rj - g[f'{i}.rot_from_json']).max() < 1e-12
+        ids = g[f'{i}.obs_ids']
+        assert abs(cm.projection_rmse(pos, R, f, f, (480., 270.), P[ids], g[f'{i}.obs']) - float(g[f'{i}.rmse'])) < 1e-9
+        ok, fx, fy = cm.k_from_plane_homography(g[f'{i}.H'])
+        assert ok == bool(g[f'{i}.k_ok'])
+        if ok:
+            assert abs(fx - float(g[f'{i}.k_fx'])) < 1e-6 * fx and abs(fy - float(g[f'{i}.k_fy'])) < 1e-6 * fy
+            assert abs(fx - f) < 1e-3 * f      # exact homography -> the true focal length comes back
+        assert cm.good_camera(f, pos) == bool(g[f'{i}.good'])
+
+
+def test_line_join_golden(gold_dir):
+    with open(os.path.join(gold_dir, 'lines.json')) as f:
+        g = json.load(f)
+    pts = ol.lines_to_keypoints({k: tuple(v) for k, v in g['lines'].items()})
+    assert {str(k) for k in pts} == set(g['keypoints'])
+    for k, v in pts.items():
+        assert np.allclose(v, g['keypoints'][str(k)])
+    assert ol.line_eq_intersection((1.0, 0.0), (1.00001, 5.0)) is None
+    assert ol.slope_intercept((1., 2.), (1., 2.)) == (None, None)

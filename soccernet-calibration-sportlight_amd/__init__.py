@@ -5,5 +5,8 @@ Import as ``import sncal_amd`` (alias module at the repo root) -- the directory 
 """
 from . import _lib  # noqa: F401
 from .transforms import HRNetPredictionTransform, EHMPredictionTransform  # noqa: F401
+from .hrnet import HRNetHeatmap, load_config  # noqa: F401
+from .metamodel import HRNetMetaModel, EHMMetaModel, load_model  # noqa: F401
 
-__all__ = ['HRNetPredictionTransform', 'EHMPredictionTransform']
+__all__ = ['HRNetPredictionTransform', 'EHMPredictionTransform', 'HRNetHeatmap', 'load_config',
+           'HRNetMetaModel', 'EHMMetaModel', 'load_model']

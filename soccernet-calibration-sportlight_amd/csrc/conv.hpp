@@ -1,0 +1,233 @@
+// Implicit-GEMM convolution on gfx950 MFMA: NHWC activations, fragment-ordered packed weights.
+//
+// Replaces the cuDNN/ATen conv + eval BatchNorm + ReLU (+ residual add) sequences the reference runs for
+// BasicBlock / Bottleneck / transition / fuse / head layers (/root/reference/src/models/hrnet/hrnet.py
+// :42-58, :79-99, :183-214, :316-329, :357-391, :450-456).  BatchNorm is folded into the packed weights
+// (scale) and the epilogue bias (shift) at load time.
+//
+// GEMM view (operands swapped so that each lane ends up with 4 consecutive output channels of one pixel
+// and can store 8/16 contiguous bytes):
+//      D[cout, pixel] = sum_k  W[cout, k] * X[k, pixel],   k = (tap, cin)
+//   A operand = weights  (M = 16 output channels per MFMA tile)
+//   B operand = pixels   (N = 16 consecutive output x of one row per MFMA tile)
+// K is walked in 16-byte "k-groups" (8 bf16 / 4 fp32 input channels of one tap); one k-step = 4 k-groups =
+// one v_mfma_f32_16x16x32_bf16, or four v_mfma_f32_16x16x4_f32 for the exact-fp32 parity path.  The four
+// k-groups of a k-step may belong to different taps, so Cin = 48 (6 k-groups per tap) packs 54 -> 56
+// k-groups instead of padding the channel count.
+//
+// Workgroup = 256 threads = 4 waves.  It owns a spatial tile of 4*NI pixel fragments (TH rows x TWF
+// fragments wide, chosen per layer so odd sizes like 135x240, 68x120, 34x60, 17x30 waste < 7 %) times
+// MI*16 output channels.  Per input-channel chunk (G k-groups per pixel) it stages
+//   - the input halo tile  [(TH-1)*S+KS] x [(16*TWF-1)*S+KS] pixels x G*16 bytes   (read once, reused by
+//     all KS*KS taps and all MI channel tiles: this is where the 9x im2col redundancy is absorbed), with
+//     a per-(G,stride) pixel pitch that makes the B-fragment ds_read_b128 bank-conflict-free;
+//   - the weight chunk, already in fragment order [k-step][mi][lane][16 B] (lane-linear, conflict-free).
+// Each wave computes NI pixel fragments x MI channel fragments: per k-step MI + NI ds_read_b128 feed
+// MI*NI MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sncal {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> { static constexpr int GE = 8; using frag = bf16x8; };
+template <> struct Elem<float> { static constexpr int GE = 4; using frag = f32x4; };
+
+struct ConvParams {
+    const void* in;        // [N][Hin][Win][Cin] T
+    void* out;             // [N][Hout][Wout][out_cstride] T (or float when out_f32), channels at out_coff
+    const void* res;       // optional residual, same indexing as out (may alias out)
+    const void* w;         // packed weights: [nblk][chunk][kstep][mi][lane] x 16 B
+    const float* bias;     // [cout_frags*16] fp32 (folded BN shift / conv bias)
+    int N, Hin, Win, Cin;
+    int Hout, Wout, cout_frags;      // cout_frags*16 = padded Cout
+    int cout;                        // real Cout (stores are masked beyond it)
+    int out_cstride, out_coff;
+    int cin_chunks;
+    int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
+    int tiles_x, tiles_y;
+    int relu, out_f32;
+};
+
+// pixel pitch (bytes) of the LDS halo tile that makes the B-fragment reads conflict-free
+// (found by enumerating the ds_read_b128 lane groups of MI355X_MICROARCH.md "LDS")
+__host__ __device__ constexpr int halo_pitch(int G, int stride) {
+    int slots = G;
+    if (stride == 1) { if (G > 1) while (slots % 4 != 2) ++slots; }
+    else { if (G > 1 && slots % 2 == 0) ++slots; }
+    return slots * 16;
+}
+
+__host__ __device__ constexpr int conv_nks(int KS, int G) { return (KS * KS * G + 3) / 4; }
+
+inline size_t conv_lds_bytes(int KS, int S, int NI, int MI, int G, int twf) {
+    const int th = 4 * NI / twf;
+    const int hh = (th - 1) * S + KS, hw = (16 * twf - 1) * S + KS;
+    return (size_t)conv_nks(KS, G) * MI * 1024 + (size_t)hh * hw * halo_pitch(G, S);
+}
+
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+    using frag = typename Elem<T>::frag;
+    constexpr int GE = Elem<T>::GE;
+    constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
+    constexpr int PS = halo_pitch(G, STRIDE);
+    constexpr int PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;
+    char* s_in = smem + NKS * MI * 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    const int n = tile / p.tiles_y;
+    const int nb = blockIdx.y;
+    const int TWF = p.twf, TH = 4 * NI / TWF;
+    const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
+    const int oy0 = ty * TH, ox0 = tx * 16 * TWF;
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    const int g = lane >> 4, ln = lane & 15;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int boff[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int f = wave * NI + j;
+        const int fr = f / TWF, fx = f - fr * TWF;
+        boff[j] = ((fr * STRIDE) * HALO_W + (fx * 16 + ln) * STRIDE) * PS;
+    }
+    const int row_pitch = HALO_W * PS;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const int npix = HALO_H * HALO_W;
+
+    for (int c = 0; c < p.cin_chunks; ++c) {
+        if (c > 0) __syncthreads();
+        {   // weight chunk: straight 16-B copy, already in fragment order
+            const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
+                                ((size_t)nb * p.cin_chunks + c) * (NKS * MI * 64);
+            for (int i = tid; i < NKS * MI * 64; i += 256) reinterpret_cast<uint4*>(s_w)[i] = wsrc[i];
+        }
+        for (int i = tid; i < npix * G; i += 256) {   // halo tile, zero-filled outside the image / Cin
+            const int pix = i / G, cg = i - pix * G;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            const int iy = iy0 + hy, ix = ix0 + hx, ch = (c * G + cg) * GE;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ch < p.Cin)
+                v = *reinterpret_cast<const uint4*>(in + (((size_t)n * p.Hin + iy) * p.Win + ix) * p.Cin + ch);
+            *reinterpret_cast<uint4*>(s_in + pix * PS + cg * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            int off;
+            if constexpr (G % 4 == 0) {          // the 4 k-groups of a k-step share one tap
+                constexpr int dummy = 0; (void)dummy;
+                const int tap = (4 * s) / G, cg0 = (4 * s) % G;
+                off = (tap / KS) * row_pitch + (tap % KS) * PS + (cg0 + g) * 16;
+            } else {
+                int kg = 4 * s + g;
+                kg = kg < NKG ? kg : NKG - 1;     // padded k-groups: weights are zero, address must stay valid
+                const int tap = kg / G, cg = kg - tap * G;
+                const int dy = tap / KS, dx = tap - dy * KS;
+                off = dy * row_pitch + dx * PS + cg * 16;
+            }
+            frag a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const frag*>(s_w + ((s * MI + mi) * 64 + lane) * 16);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (GE == 8) {
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[j], acc[mi][j], 0, 0, 0);
+                    } else {
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][0], b[j][0], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][1], b[j][1], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][2], b[j][2], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][3], b[j][3], acc[mi][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // epilogue: + folded-BN shift (+ residual) (ReLU) -> store 4 consecutive channels per lane
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int f = wave * NI + j;
+        const int fr = f / TWF, fx = f - fr * TWF;
+        const int oy = oy0 + fr, ox = ox0 + fx * 16 + ln;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int cf = nb * MI + mi;
+            if (cf >= p.cout_frags) continue;
+            const int co = cf * 16 + g * 4;
+            if (co >= p.cout) continue;                    // padded output channels are never stored
+            const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
+            float v0 = acc[mi][j][0] + bs.x, v1 = acc[mi][j][1] + bs.y;
+            float v2 = acc[mi][j][2] + bs.z, v3 = acc[mi][j][3] + bs.w;
+            const size_t o = pix * p.out_cstride + p.out_coff + co;
+            if (p.res) {
+                if constexpr (GE == 8) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.res) + o);
+                    v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                } else {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + o);
+                    v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                }
+            }
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            if (p.out_f32 || GE == 4) {
+                float* dst = reinterpret_cast<float*>(p.out) + o;
+                if (co + 4 <= p.cout) *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+                else { dst[0] = v0; if (co + 1 < p.cout) dst[1] = v1; if (co + 2 < p.cout) dst[2] = v2; }
+            } else {
+                bf16x4 q;
+                q[0] = (__bf16)v0; q[1] = (__bf16)v1; q[2] = (__bf16)v2; q[3] = (__bf16)v3;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + o) = q;
+            }
+        }
+    }
+}
+
+// host-visible launcher table ---------------------------------------------------------------------
+typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream_t s);
+
+struct ConvVariant {
+    int dtype;      // SNCAL_F32 / SNCAL_BF16
+    int ks, stride, ni, mi, g;
+    ConvLaunchFn launch;
+};
+
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
+}
+
+// registries filled by conv_bf16.hip / conv_f32.hip
+const ConvVariant* conv_variants_bf16(int* n);
+const ConvVariant* conv_variants_f32(int* n);
+
+}  // namespace sncal

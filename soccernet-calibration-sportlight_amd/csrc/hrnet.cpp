@@ -1,0 +1,638 @@
+// HRNet plan builder + executor behind the sncal_hrnet_* C ABI.
+//
+// Mirrors the topology of HighResolutionNet (/root/reference/src/models/hrnet/hrnet.py:255-355 for the
+// construction order / state-dict names, :437-511 for the forward) and of the line network
+// (/root/reference/src/models/line/hrnet.py:30-249).  The network is lowered once into a flat list of
+// ops over NHWC tensors:
+//     INPUT   NCHW fp32 frames -> NHWC (channel-padded to one 16-byte k-group)
+//     CONV    MFMA implicit-GEMM conv with folded BN, optional residual + ReLU   (conv.hpp)
+//     UPADD   out = [relu](base + sum bilinear_up(src_i)); also used to write upsampled branches into a
+//             channel slice of the head's concat tensor                             (ops.hip)
+//     SOFTMAX NHWC fp32 logits -> NCHW fp32 (log-)softmax heatmaps
+//     DECODE  D1 keypoint decode (decode.hip)
+// Tensors get offsets inside one caller-provided workspace from a lifetime-based first-fit allocator, so a
+// forward is a fixed sequence of kernel launches with no allocation.  Frames are processed in sub-batches
+// (SNCAL_SUBBATCH, default 8) so that the activations of a sub-batch stay Infinity-Cache sized.
+#include "common.hpp"
+#include "conv.hpp"
+#include "ops.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+extern "C" int sncal_heatmap_decode(const float*, int, int, int, int, int, int, float*, void*);
+
+namespace sncal {
+
+struct ConvLayer {
+    std::string name, bn;
+    int cin, cout, k, stride;
+    bool bias;
+    // host weights (BN folded on set)
+    std::vector<float> w, scale, shift;
+    bool is_set = false;
+    // packing / dispatch
+    int cin_phys = 0, mi = 0, g = 0, chunks = 0, nblk = 0, cout_frags = 0;
+    void* d_w = nullptr;
+    float* d_bias = nullptr;
+};
+
+enum OpType { OP_INPUT, OP_CONV, OP_UPADD, OP_SOFTMAX, OP_DECODE };
+
+struct Op {
+    OpType type;
+    int conv = -1;
+    int in = -1, out = -1, res = -1;
+    bool relu = false;
+    int out_coff = 0;
+    bool out_f32 = false;
+    int base = -1, srcs[3] = {-1, -1, -1}, nsrc = 0;
+    int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
+};
+
+struct Tensor {
+    int C = 0;
+    bool f32 = false;         // fp32 storage regardless of the net dtype (logits / heat)
+    bool external_heat = false;
+    int first = -1, last = -1;   // producing / last consuming op
+    // per-run
+    int H = 0, W = 0;
+    size_t offset = 0, bytes = 0;
+};
+
+}  // namespace sncal
+
+using namespace sncal;
+
+struct sncal_hrnet {
+    sncal_hrnet_desc desc;
+    int dtype;
+    int ge;          // elements per 16-byte k-group
+    int esize;
+    std::vector<ConvLayer> layers;
+    std::map<std::string, int> layer_by_name;
+    std::vector<Op> ops;
+    std::vector<Tensor> tensors;
+    int t_heat = -1, t_kpts_src = -1;
+    bool finalized = false;
+    int subbatch = 8;
+    const ConvVariant* variants = nullptr;
+    int nvariants = 0;
+    // cached per-(sb,H,W) layout
+    int lay_sb = -1, lay_h = -1, lay_w = -1;
+    size_t lay_bytes = 0;
+};
+
+namespace {
+
+std::string fmt(const char* f, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return buf;
+}
+
+struct Builder {
+    sncal_hrnet& net;
+    explicit Builder(sncal_hrnet& n) : net(n) {}
+
+    int add_layer(const std::string& name, const std::string& bn, int cin, int cout, int k, int stride, bool bias) {
+        ConvLayer L;
+        L.name = name; L.bn = bn; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.bias = bias;
+        net.layers.push_back(L);
+        net.layer_by_name[name] = (int)net.layers.size() - 1;
+        return (int)net.layers.size() - 1;
+    }
+    int new_tensor(int C, bool f32 = false) {
+        Tensor t; t.C = C; t.f32 = f32;
+        net.tensors.push_back(t);
+        return (int)net.tensors.size() - 1;
+    }
+    int conv(const std::string& name, int in, bool relu, int res = -1, bool out_f32 = false) {
+        auto it = net.layer_by_name.find(name);
+        if (it == net.layer_by_name.end()) { set_error("internal: conv %s not enumerated", name.c_str()); return -1; }
+        const ConvLayer& L = net.layers[it->second];
+        Op op; op.type = OP_CONV; op.conv = it->second; op.in = in; op.res = res; op.relu = relu; op.out_f32 = out_f32;
+        const int cphys = out_f32 ? ((L.cout + 15) / 16) * 16 : L.cout;
+        op.out = new_tensor(cphys, out_f32);
+        net.ops.push_back(op);
+        return op.out;
+    }
+    int upadd(int base, const std::vector<int>& srcs, bool relu, int C) {
+        Op op; op.type = OP_UPADD; op.base = base; op.nsrc = (int)srcs.size(); op.relu = relu;
+        for (size_t i = 0; i < srcs.size(); ++i) op.srcs[i] = srcs[i];
+        op.out = new_tensor(C);
+        net.ops.push_back(op);
+        return op.out;
+    }
+    void concat_part(int cat, int src, int coff, int dims_from, int dims_mul) {
+        Op op; op.type = OP_UPADD; op.base = -1; op.nsrc = 1; op.srcs[0] = src; op.out = cat; op.out_coff = coff;
+        op.dims_from = dims_from; op.dims_mul = dims_mul;
+        net.ops.push_back(op);
+    }
+
+    // ---- enumeration in the reference's registration order (hrnet.py:255-355) -------------------------
+    void block_layers(const std::string& p, bool bottleneck, int inpl, int planes, bool ds) {
+        if (!bottleneck) {
+            add_layer(p + ".conv1", p + ".bn1", inpl, planes, 3, 1, false);
+            add_layer(p + ".conv2", p + ".bn2", planes, planes, 3, 1, false);
+            if (ds) add_layer(p + ".downsample.0", p + ".downsample.1", inpl, planes, 1, 1, false);
+        } else {
+            add_layer(p + ".conv1", p + ".bn1", inpl, planes, 1, 1, false);
+            add_layer(p + ".conv2", p + ".bn2", planes, planes, 3, 1, false);
+            add_layer(p + ".conv3", p + ".bn3", planes, planes * 4, 1, 1, false);
+            if (ds) add_layer(p + ".downsample.0", p + ".downsample.1", inpl, planes * 4, 1, 1, false);
+        }
+    }
+
+    void enumerate() {
+        const sncal_hrnet_desc& d = net.desc;
+        const std::string P = "model.";
+        add_layer(P + "conv1", P + "bn1", 3, d.stem_width, 3, 2, false);
+        add_layer(P + "conv2", P + "bn2", d.stem_width, d.stem_width, 3, 2, false);
+        int inpl = 64;   // hard-coded in the reference (hrnet.py:273)
+        for (int b = 0; b < d.stage1_blocks; ++b) {
+            const bool ds = b == 0 && inpl != d.stage1_channels * 4;
+            block_layers(fmt("%slayer1.%d", P.c_str(), b), true, inpl, d.stage1_channels, ds);
+            inpl = d.stage1_channels * 4;
+        }
+        std::vector<int> pre{inpl};
+        for (int si = 0; si < 3; ++si) {
+            const int nb = d.num_branches[si];
+            std::vector<int> cur(d.num_channels[si], d.num_channels[si] + nb);
+            const std::string tn = fmt("%stransition%d", P.c_str(), si + 1);
+            for (int i = 0; i < nb; ++i) {
+                if (i < (int)pre.size()) {
+                    if (cur[i] != pre[i])
+                        add_layer(fmt("%s.%d.0", tn.c_str(), i), fmt("%s.%d.1", tn.c_str(), i), pre[i], cur[i], 3, 1, false);
+                } else {
+                    for (int j = 0; j < i + 1 - (int)pre.size(); ++j) {
+                        const int cin = pre.back();
+                        const int cout = (j == i - (int)pre.size()) ? cur[i] : cin;
+                        add_layer(fmt("%s.%d.%d.0", tn.c_str(), i, j), fmt("%s.%d.%d.1", tn.c_str(), i, j), cin, cout, 3, 2, false);
+                    }
+                }
+            }
+            std::vector<int> inch = cur;
+            for (int m = 0; m < d.num_modules[si]; ++m) {
+                const std::string mn = fmt("%sstage%d.%d", P.c_str(), si + 2, m);
+                for (int br = 0; br < nb; ++br)
+                    for (int b = 0; b < d.num_blocks[si]; ++b) {
+                        const int ch = d.num_channels[si][br];
+                        block_layers(fmt("%s.branches.%d.%d", mn.c_str(), br, b), false, inch[br], ch, b == 0 && inch[br] != ch);
+                        inch[br] = ch;
+                    }
+                for (int i = 0; i < nb; ++i)
+                    for (int j = 0; j < nb; ++j) {
+                        const std::string fn = fmt("%s.fuse_layers.%d.%d", mn.c_str(), i, j);
+                        if (j > i) add_layer(fn + ".0", fn + ".1", inch[j], inch[i], 1, 1, false);
+                        else if (j < i)
+                            for (int k = 0; k < i - j; ++k) {
+                                const int cout = (k == i - j - 1) ? inch[i] : inch[j];
+                                add_layer(fmt("%s.%d.0", fn.c_str(), k), fmt("%s.%d.1", fn.c_str(), k), inch[j], cout, 3, 2, false);
+                            }
+                    }
+            }
+            pre = inch;
+        }
+        int last = 0;
+        for (int c : pre) last += c;
+        if (d.upscale > 1) last += d.stem_width;
+        add_layer(P + "last_layer.0", P + "last_layer.1", last, last, 1, 1, true);
+        add_layer(P + "last_layer.3", "", last, d.num_classes, 1, 1, true);
+    }
+
+    // ---- op graph (hrnet.py:437-511) -----------------------------------------------------------------
+    int basic_block(const std::string& p, int x) {   // hrnet.py:42-58
+        const int t = conv(p + ".conv1", x, true);
+        int res = x;
+        if (net.layer_by_name.count(p + ".downsample.0")) res = conv(p + ".downsample.0", x, false);
+        return conv(p + ".conv2", t, true, res);
+    }
+    int bottleneck(const std::string& p, int x) {    // hrnet.py:79-99
+        int t = conv(p + ".conv1", x, true);
+        t = conv(p + ".conv2", t, true);
+        int res = x;
+        if (net.layer_by_name.count(p + ".downsample.0")) res = conv(p + ".downsample.0", x, false);
+        return conv(p + ".conv3", t, true, res);
+    }
+
+    bool build() {
+        const sncal_hrnet_desc& d = net.desc;
+        const std::string P = "model.";
+        enumerate();
+        const int t_in = new_tensor(net.ge);
+        { Op op; op.type = OP_INPUT; op.out = t_in; net.ops.push_back(op); }
+        const int t_stem = conv(P + "conv1", t_in, true);
+        int x = conv(P + "conv2", t_stem, true);
+        for (int b = 0; b < d.stage1_blocks; ++b) x = bottleneck(fmt("%slayer1.%d", P.c_str(), b), x);
+        std::vector<int> ys{x};
+        for (int si = 0; si < 3; ++si) {
+            const int nb = d.num_branches[si];
+            const std::string tn = fmt("%stransition%d", P.c_str(), si + 1);
+            std::vector<int> xs;
+            for (int i = 0; i < nb; ++i) {
+                if (i < (int)ys.size()) {
+                    if (net.layer_by_name.count(fmt("%s.%d.0", tn.c_str(), i))) xs.push_back(conv(fmt("%s.%d.0", tn.c_str(), i), ys[i], true));
+                    else xs.push_back(ys[i]);
+                } else {
+                    int t = ys.back();
+                    for (int j = 0; j < i + 1 - (int)ys.size(); ++j) t = conv(fmt("%s.%d.%d.0", tn.c_str(), i, j), t, true);
+                    xs.push_back(t);
+                }
+            }
+            for (int m = 0; m < d.num_modules[si]; ++m) {
+                const std::string mn = fmt("%sstage%d.%d", P.c_str(), si + 2, m);
+                for (int br = 0; br < nb; ++br)
+                    for (int b = 0; b < d.num_blocks[si]; ++b) xs[br] = basic_block(fmt("%s.branches.%d.%d", mn.c_str(), br, b), xs[br]);
+                std::vector<int> out(nb);
+                for (int i = 0; i < nb; ++i) {                       // hrnet.py:229-244
+                    int acc = xs[i];
+                    const bool has_up = i < nb - 1;
+                    for (int j = 0; j < i; ++j) {                    // fuse-down chains end with an accumulate
+                        const std::string fn = fmt("%s.fuse_layers.%d.%d", mn.c_str(), i, j);
+                        int t = xs[j];
+                        for (int k = 0; k < i - j; ++k) {
+                            const bool lastk = k == i - j - 1;
+                            if (!lastk) t = conv(fmt("%s.%d.0", fn.c_str(), k), t, true);
+                            else acc = conv(fmt("%s.%d.0", fn.c_str(), k), t, /*relu=*/!has_up && j == i - 1, acc);
+                        }
+                    }
+                    if (has_up) {
+                        std::vector<int> ups;
+                        for (int j = i + 1; j < nb; ++j) ups.push_back(conv(fmt("%s.fuse_layers.%d.%d.0", mn.c_str(), i, j), xs[j], false));
+                        acc = upadd(acc, ups, true, net.tensors[xs[i]].C);
+                    }
+                    out[i] = acc;
+                }
+                xs = out;
+            }
+            ys = xs;
+        }
+        // head: upsample + concat (hrnet.py:489-509; line/hrnet.py:236-245)
+        int catC = 0;
+        for (int t : ys) catC += net.tensors[t].C;
+        if (d.upscale > 1) catC += d.stem_width;
+        const int cat = new_tensor(catC);
+        int coff = 0;
+        if (d.upscale > 1) { concat_part(cat, t_stem, coff, ys[0], d.upscale); coff += d.stem_width; }
+        for (int t : ys) { concat_part(cat, t, coff, ys[0], d.upscale); coff += net.tensors[t].C; }
+        const int hid = conv(P + "last_layer.0", cat, true);
+        const int logits = conv(P + "last_layer.3", hid, false, -1, true);
+        { Op op; op.type = OP_SOFTMAX; op.in = logits; op.out = new_tensor(d.num_classes, true);
+          net.tensors[op.out].external_heat = true; net.t_heat = op.out; net.ops.push_back(op); }
+        { Op op; op.type = OP_DECODE; op.in = net.t_heat; net.ops.push_back(op); }
+        // lifetimes
+        for (size_t i = 0; i < net.ops.size(); ++i) {
+            const Op& op = net.ops[i];
+            auto use = [&](int t) { if (t >= 0) net.tensors[t].last = (int)i; };
+            use(op.in); use(op.res); use(op.base);
+            for (int s = 0; s < op.nsrc; ++s) use(op.srcs[s]);
+            if (op.out >= 0) { Tensor& t = net.tensors[op.out]; if (t.first < 0) t.first = (int)i; t.last = std::max(t.last, (int)i); }
+            if (op.dims_from >= 0) use(op.dims_from);
+        }
+        return true;
+    }
+};
+
+// choose (MI, G) for a layer: maximise useful/padded work x operand reuse among the instantiated variants
+void choose_packing(sncal_hrnet& net, ConvLayer& L) {
+    const int ge = net.ge;
+    const int cout_frags = (L.cout + 15) / 16;
+    double best = -1;
+    for (int v = 0; v < net.nvariants; ++v) {
+        const ConvVariant& V = net.variants[v];
+        if (V.ks != L.k || V.stride != L.stride) continue;
+        const int chunks = (L.cin_phys + V.g * ge - 1) / (V.g * ge);
+        const int nks = conv_nks(V.ks, V.g);
+        const double k_eff = (double)(L.k * L.k * L.cin_phys / ge) / (double)(chunks * nks * 4);
+        const int nblk = (cout_frags + V.mi - 1) / V.mi;
+        const double m_eff = (double)cout_frags / (nblk * V.mi);
+        const double reuse = (double)(V.mi * 4) / (V.mi + 4);           // MFMAs per LDS fragment read (NI=4 nominal)
+        const double per_chunk = (double)nks / (nks + 1.0);              // amortisation of the per-chunk sync/load
+        const double score = k_eff * m_eff * (0.55 + 0.45 * reuse / 2.4) * per_chunk;
+        if (score > best + 1e-9) { best = score; L.mi = V.mi; L.g = V.g; }
+    }
+    L.cout_frags = cout_frags;
+    L.nblk = (cout_frags + L.mi - 1) / L.mi;
+    L.chunks = (L.cin_phys + L.g * ge - 1) / (L.g * ge);
+}
+
+inline uint16_t f2bf(float f) {   // round-to-nearest-even
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int pack_layer(sncal_hrnet& net, ConvLayer& L) {
+    const int ge = net.ge, KS = L.k, G = L.g, MI = L.mi;
+    const int nks = conv_nks(KS, G);
+    const size_t n16 = (size_t)L.nblk * L.chunks * nks * MI * 64;       // 16-byte vectors
+    std::vector<uint8_t> host(n16 * 16, 0);
+    for (int nb = 0; nb < L.nblk; ++nb)
+        for (int c = 0; c < L.chunks; ++c)
+            for (int s = 0; s < nks; ++s)
+                for (int mi = 0; mi < MI; ++mi)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 15, g = lane >> 4;
+                        const int kg = 4 * s + g;
+                        const int tap = kg / G, cgi = kg % G;
+                        const int co = (nb * MI + mi) * 16 + m;
+                        uint8_t* dst = host.data() + ((((size_t)(nb * L.chunks + c) * nks + s) * MI + mi) * 64 + lane) * 16;
+                        if (tap >= KS * KS || co >= L.cout) continue;
+                        for (int e = 0; e < ge; ++e) {
+                            const int ci = (c * G + cgi) * ge + e;
+                            if (ci >= L.cin) continue;
+                            const float v = L.w[(((size_t)co * L.cin + ci) * KS + tap / KS) * KS + tap % KS] * L.scale[co];
+                            if (net.dtype == SNCAL_BF16) { const uint16_t b = f2bf(v); memcpy(dst + e * 2, &b, 2); }
+                            else memcpy(dst + e * 4, &v, 4);
+                        }
+                    }
+    std::vector<float> bias((size_t)L.nblk * MI * 16, 0.f);
+    for (int co = 0; co < L.cout; ++co) bias[co] = L.shift[co];
+    if (L.d_w) { (void)hipFree(L.d_w); L.d_w = nullptr; }
+    if (L.d_bias) { (void)hipFree(L.d_bias); L.d_bias = nullptr; }
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w, host.size()));
+    SNCAL_CHECK_HIP(hipMalloc((void**)&L.d_bias, bias.size() * sizeof(float)));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w, host.data(), host.size(), hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SNCAL_OK;
+}
+
+// shape inference + workspace layout for a sub-batch of `sb` frames of HxW
+int layout(sncal_hrnet& net, int sb, int H, int W) {
+    if (net.lay_sb == sb && net.lay_h == H && net.lay_w == W) return SNCAL_OK;
+    std::vector<Tensor>& T = net.tensors;
+    for (const Op& op : net.ops) {
+        switch (op.type) {
+            case OP_INPUT: T[op.out].H = H; T[op.out].W = W; break;
+            case OP_CONV: {
+                const ConvLayer& L = net.layers[op.conv];
+                const int pad = L.k / 2;
+                T[op.out].H = (T[op.in].H + 2 * pad - L.k) / L.stride + 1;
+                T[op.out].W = (T[op.in].W + 2 * pad - L.k) / L.stride + 1;
+                break;
+            }
+            case OP_UPADD:
+                if (op.base >= 0) { T[op.out].H = T[op.base].H; T[op.out].W = T[op.base].W; }
+                else { T[op.out].H = T[op.dims_from].H * op.dims_mul; T[op.out].W = T[op.dims_from].W * op.dims_mul; }
+                break;
+            case OP_SOFTMAX: T[op.out].H = T[op.in].H; T[op.out].W = T[op.in].W; break;
+            case OP_DECODE: break;
+        }
+    }
+    // first-fit allocator over op order
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_list;
+    size_t top = 0;
+    auto alloc = [&](size_t bytes) -> size_t {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].size >= bytes) {
+                const size_t off = free_list[i].off;
+                free_list[i].off += bytes; free_list[i].size -= bytes;
+                if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+                return off;
+            }
+        const size_t off = top; top += bytes; return off;
+    };
+    auto release = [&](size_t off, size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        free_list.push_back({off, bytes});
+        std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_list.size();)
+            if (free_list[i].off + free_list[i].size == free_list[i + 1].off) { free_list[i].size += free_list[i + 1].size; free_list.erase(free_list.begin() + i + 1); }
+            else ++i;
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) { top = free_list.back().off; free_list.pop_back(); }
+    };
+    for (size_t i = 0; i < net.ops.size(); ++i) {
+        for (size_t t = 0; t < T.size(); ++t)
+            if (T[t].first == (int)i) {
+                T[t].bytes = (size_t)sb * T[t].H * T[t].W * T[t].C * (T[t].f32 ? 4 : net.esize);
+                T[t].offset = alloc(T[t].bytes);
+            }
+        for (size_t t = 0; t < T.size(); ++t)
+            if (T[t].last == (int)i && T[t].first >= 0) release(T[t].offset, T[t].bytes);
+    }
+    // peak = max end offset
+    size_t peak = 0;
+    for (const Tensor& t : T) if (t.first >= 0) peak = std::max(peak, t.offset + ((t.bytes + 255) & ~(size_t)255));
+    net.lay_bytes = peak;
+    net.lay_sb = sb; net.lay_h = H; net.lay_w = W;
+    return SNCAL_OK;
+}
+
+int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t stream) {
+    const ConvLayer& L = net.layers[op.conv];
+    const Tensor& ti = net.tensors[op.in];
+    const Tensor& to = net.tensors[op.out];
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = ws + ti.offset; p.out = ws + to.offset;
+    p.res = op.res >= 0 ? ws + net.tensors[op.res].offset : nullptr;
+    p.w = L.d_w; p.bias = L.d_bias;
+    p.N = sb; p.Hin = ti.H; p.Win = ti.W; p.Cin = ti.C;
+    p.Hout = to.H; p.Wout = to.W; p.cout_frags = L.cout_frags; p.cout = L.cout;
+    p.out_cstride = to.C; p.out_coff = op.out_coff;
+    p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
+    // pick NI / tile shape for this spatial size
+    const ConvVariant* bestv = nullptr;
+    int best_twf = 1; double best_score = -1; size_t best_lds = 0;
+    for (int v = 0; v < net.nvariants; ++v) {
+        const ConvVariant& V = net.variants[v];
+        if (V.ks != L.k || V.stride != L.stride || V.mi != L.mi || V.g != L.g) continue;
+        const int F = 4 * V.ni;
+        for (int twf = 1; twf <= F; twf *= 2) {
+            const int th = F / twf;
+            const size_t lds = conv_lds_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
+            if (lds > 160 * 1024) continue;
+            const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
+            const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
+            const long blocks = ty * tx * sb * L.nblk;
+            const double fill = std::min(1.0, (double)blocks / 512.0);        // keep >= 2 workgroups per CU busy
+            const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);
+            const double occ = lds <= 80 * 1024 ? 1.0 : 0.9;
+            const double score = eff * (0.5 + 0.5 * fill) * (0.6 + 0.4 * reuse / 2.4) * occ;
+            if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; }
+        }
+    }
+    if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
+    const int th = 4 * bestv->ni / best_twf;
+    p.twf = best_twf;
+    p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
+    p.tiles_y = (to.H + th - 1) / th;
+    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+}  // namespace
+
+extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out) {
+    SNCAL_CHECK_ARG(desc && out, "sncal_hrnet_create: null pointer");
+    SNCAL_CHECK_ARG(dtype == SNCAL_F32 || dtype == SNCAL_BF16, "sncal_hrnet_create: dtype %d", dtype);
+    SNCAL_CHECK_ARG(desc->stem_width == 64, "stem_width must be 64 (layer1 input is hard-coded, hrnet.py:273)");
+    SNCAL_CHECK_ARG(desc->num_classes >= 2 && desc->num_classes <= 64, "num_classes %d out of range", desc->num_classes);
+    SNCAL_CHECK_ARG(desc->upscale == 1 || desc->upscale == 2, "upscale must be 1 or 2");
+    for (int s = 0; s < 3; ++s) {
+        SNCAL_CHECK_ARG(desc->num_branches[s] == s + 2, "stage%d must have %d branches", s + 2, s + 2);
+        SNCAL_CHECK_ARG(desc->num_modules[s] >= 1 && desc->num_blocks[s] >= 1, "stage%d: modules/blocks", s + 2);
+        for (int b = 0; b < desc->num_branches[s]; ++b)
+            SNCAL_CHECK_ARG(desc->num_channels[s][b] > 0 && desc->num_channels[s][b] % 16 == 0,
+                            "stage%d branch %d: width %d must be a multiple of 16", s + 2, b, desc->num_channels[s][b]);
+    }
+    SNCAL_CHECK_ARG(desc->stage1_blocks >= 1 && desc->stage1_channels % 16 == 0, "stage1 config");
+    sncal_hrnet* net = new sncal_hrnet();
+    net->desc = *desc;
+    net->dtype = dtype;
+    net->ge = dtype == SNCAL_BF16 ? 8 : 4;
+    net->esize = dtype == SNCAL_BF16 ? 2 : 4;
+    net->variants = dtype == SNCAL_BF16 ? conv_variants_bf16(&net->nvariants) : conv_variants_f32(&net->nvariants);
+    if (const char* e = getenv("SNCAL_SUBBATCH")) { const int v = atoi(e); if (v > 0) net->subbatch = v; }
+    Builder b(*net);
+    if (!b.build()) { delete net; return SNCAL_ERR_STATE; }
+    *out = net;
+    return SNCAL_OK;
+}
+
+extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
+    if (!net) return;
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); }
+    delete net;
+}
+
+extern "C" int sncal_hrnet_num_convs(const sncal_hrnet* net) { return net ? (int)net->layers.size() : 0; }
+
+extern "C" int sncal_hrnet_conv_info(const sncal_hrnet* net, int idx, char* name, int name_cap, char* bn_name, int bn_cap,
+                                     int* cin, int* cout, int* ksize, int* stride, int* has_bias) {
+    SNCAL_CHECK_ARG(net && idx >= 0 && idx < (int)net->layers.size(), "sncal_hrnet_conv_info: index %d", idx);
+    const ConvLayer& L = net->layers[idx];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", L.name.c_str());
+    if (bn_name && bn_cap > 0) snprintf(bn_name, bn_cap, "%s", L.bn.c_str());
+    if (cin) *cin = L.cin;
+    if (cout) *cout = L.cout;
+    if (ksize) *ksize = L.k;
+    if (stride) *stride = L.stride;
+    if (has_bias) *has_bias = L.bias ? 1 : 0;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_weight, const float* h_scale, const float* h_shift) {
+    SNCAL_CHECK_ARG(net && idx >= 0 && idx < (int)net->layers.size(), "sncal_hrnet_set_conv: index %d", idx);
+    SNCAL_CHECK_ARG(h_weight && h_shift, "sncal_hrnet_set_conv: null weights");
+    ConvLayer& L = net->layers[idx];
+    const size_t nw = (size_t)L.cout * L.cin * L.k * L.k;
+    L.w.assign(h_weight, h_weight + nw);
+    L.scale.assign(L.cout, 1.0f);
+    if (h_scale) L.scale.assign(h_scale, h_scale + L.cout);
+    L.shift.assign(h_shift, h_shift + L.cout);
+    L.is_set = true;
+    net->finalized = false;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_finalize: null");
+    // physical Cin of every conv = channel count of its input tensor
+    for (const Op& op : net->ops)
+        if (op.type == OP_CONV) net->layers[op.conv].cin_phys = net->tensors[op.in].C;
+    for (ConvLayer& L : net->layers) {
+        if (!L.is_set) { set_error("conv %s has no weights", L.name.c_str()); return SNCAL_ERR_STATE; }
+        choose_packing(*net, L);
+        if (L.mi == 0) { set_error("no kernel variant for conv %s (k=%d s=%d)", L.name.c_str(), L.k, L.stride); return SNCAL_ERR_STATE; }
+        const int rc = pack_layer(*net, L);
+        if (rc) return rc;
+        std::vector<float>().swap(L.w);
+    }
+    net->finalized = true;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_output_size(const sncal_hrnet* net, int H, int W, int* out_h, int* out_w) {
+    SNCAL_CHECK_ARG(net && H >= 32 && W >= 32, "sncal_hrnet_output_size: bad arguments");
+    auto half = [](int v) { return (v + 2 - 3) / 2 + 1; };
+    const int h4 = half(half(H)), w4 = half(half(W));
+    if (out_h) *out_h = h4 * net->desc.upscale;
+    if (out_w) *out_w = w4 * net->desc.upscale;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_workspace(const sncal_hrnet* cnet, int B, int H, int W, size_t* bytes) {
+    SNCAL_CHECK_ARG(cnet && bytes && B >= 0 && H >= 32 && W >= 32, "sncal_hrnet_workspace: bad arguments");
+    sncal_hrnet* net = const_cast<sncal_hrnet*>(cnet);
+    const int sb = std::max(1, std::min(B, net->subbatch));
+    const int rc = layout(*net, sb, H, W);
+    if (rc) return rc;
+    *bytes = net->lay_bytes;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
+                                   int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_forward: null net");
+    if (!net->finalized) { set_error("sncal_hrnet_forward: weights not finalized"); return SNCAL_ERR_STATE; }
+    SNCAL_CHECK_ARG(B >= 0 && H >= 32 && W >= 32, "sncal_hrnet_forward: bad shape B=%d H=%d W=%d", B, H, W);
+    if (B == 0) return SNCAL_OK;
+    SNCAL_CHECK_ARG(d_x && d_ws, "sncal_hrnet_forward: null input / workspace");
+    SNCAL_CHECK_ARG(d_heat || d_kpts, "sncal_hrnet_forward: need d_heat or d_kpts");
+    SNCAL_CHECK_ARG(!(d_kpts && net->desc.head_softmax), "sncal_hrnet_forward: keypoint decode needs a log-softmax head");
+    hipStream_t stream = as_stream(stream_);
+    const int SB = std::max(1, std::min(B, net->subbatch));
+    int rc = layout(*net, SB, H, W);
+    if (rc) return rc;
+    if (ws_bytes < net->lay_bytes) { set_error("workspace too small: %zu < %zu", ws_bytes, net->lay_bytes); return SNCAL_ERR_WORKSPACE; }
+    char* ws = reinterpret_cast<char*>(d_ws);
+    const Tensor& th = net->tensors[net->t_heat];
+    const int C = net->desc.num_classes;
+    for (int b0 = 0; b0 < B; b0 += SB) {
+        const int sb = std::min(SB, B - b0);
+        float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
+        for (const Op& op : net->ops) {
+            switch (op.type) {
+                case OP_INPUT:
+                    rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
+                    break;
+                case OP_CONV: rc = run_conv(*net, op, sb, ws, stream); break;
+                case OP_UPADD: {
+                    const Tensor& to = net->tensors[op.out];
+                    UpsampleAddParams p;
+                    memset(&p, 0, sizeof(p));
+                    p.base = op.base >= 0 ? ws + net->tensors[op.base].offset : nullptr;
+                    p.nsrc = op.nsrc;
+                    int C0 = to.C;
+                    for (int s = 0; s < op.nsrc; ++s) {
+                        const Tensor& ts = net->tensors[op.srcs[s]];
+                        p.src[s] = ws + ts.offset; p.Hs[s] = ts.H; p.Ws[s] = ts.W;
+                        p.sy[s] = to.H > 1 ? (float)(ts.H - 1) / (float)(to.H - 1) : 0.f;
+                        p.sx[s] = to.W > 1 ? (float)(ts.W - 1) / (float)(to.W - 1) : 0.f;
+                        C0 = ts.C;
+                    }
+                    p.out = ws + to.offset; p.N = sb; p.H = to.H; p.W = to.W; p.C = C0;
+                    p.out_cstride = to.C; p.out_coff = op.out_coff; p.relu = op.relu ? 1 : 0;
+                    rc = launch_upsample_add(net->dtype, p, stream);
+                    break;
+                }
+                case OP_SOFTMAX: {
+                    const Tensor& tl = net->tensors[op.in];
+                    rc = launch_softmax_nchw(reinterpret_cast<const float*>(ws + tl.offset), tl.C, C, (size_t)sb * tl.H * tl.W,
+                                             (size_t)tl.H * tl.W, net->desc.head_softmax ? 0 : 1, heat, stream);
+                    break;
+                }
+                case OP_DECODE:
+                    if (d_kpts) rc = sncal_heatmap_decode(heat, sb, C, th.H, th.W, img_h, img_w, d_kpts + (size_t)b0 * (C - 1) * 3, stream_);
+                    break;
+            }
+            if (rc) return rc;
+        }
+    }
+    return SNCAL_OK;
+}

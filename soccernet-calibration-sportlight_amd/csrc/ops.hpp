@@ -1,0 +1,25 @@
+// Launchers of the memory-bound helper kernels (ops.hip) used by the HRNet plan executor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace sncal {
+
+struct UpsampleAddParams {
+    const void* base;        // optional [N][H][W][C] tensor added to the sum (NULL = 0)
+    const void* src[3];      // up to 3 low-resolution sources [N][Hs][Ws][C]
+    int Hs[3], Ws[3];
+    float sy[3], sx[3];      // align_corners=True scales (in-1)/(out-1)
+    int nsrc;
+    void* out;               // [N][H][W][out_cstride], channels written at out_coff
+    int N, H, W, C;
+    int out_cstride, out_coff;
+    int relu;
+};
+
+int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s);
+int launch_upsample_add(int dtype, const UpsampleAddParams& p, hipStream_t s);
+int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_total, size_t hw, int log_mode,
+                        float* out, hipStream_t s);
+
+}  // namespace sncal

@@ -1,0 +1,187 @@
+"""HRNet keypoint / line networks on libsncal.so -- host mirror of the reference modules.
+
+HRNetHeatmap  <->  /root/reference/src/models/hrnet/model.py:130-150 and
+                   /root/reference/src/models/line/model.py:127-147 (num_refinement_stages == 0, the only
+                   value any shipped config uses: train_config.yaml:34, val_config.yaml:27)
+The object is callable like the reference nn.Module (``net(x)[-1]`` is the (B,C,h,w) head output) and loads
+the reference's state dict (``model.`` prefix, SyncBatchNorm running stats) -- eval-mode BatchNorm is folded
+into the conv weights before they are packed for the MFMA kernels.  PyTorch only provides device memory.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib
+
+_CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs')
+BN_EPS = 1e-5
+DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+
+def load_config(name_or_path):
+    """yaml with the reference's field names (src/models/hrnet/model_config/*.yaml)."""
+    if isinstance(name_or_path, dict):
+        cfg = dict(name_or_path)
+    else:
+        path = name_or_path if os.path.exists(str(name_or_path)) else os.path.join(_CFG_DIR, f'{name_or_path}.yaml')
+        with open(path) as f:
+            cfg = yaml.safe_load(f)
+    cfg.setdefault('upscale', 1)
+    cfg.setdefault('head', 'logsoftmax')
+    return cfg
+
+
+def _desc(cfg):
+    d = _lib.HRNetDesc()
+    d.num_classes = int(cfg['num_classes'])
+    d.stem_width = int(cfg['stem_width'])
+    d.upscale = int(cfg.get('upscale', 1) or 1)
+    d.head_softmax = 1 if cfg.get('head', 'logsoftmax') == 'softmax' else 0
+    if cfg.get('internal_final_conv', 0):
+        raise _lib.SncalError('internal_final_conv != 0 is not supported (unused by every shipped config)')
+    if int(cfg.get('final_conv_kernel', 1)) != 1:
+        raise _lib.SncalError('final_conv_kernel must be 1')
+    s1 = cfg['stage1']
+    if s1['block_type'] != 'BOTTLENECK':
+        raise _lib.SncalError('stage1 must use BOTTLENECK blocks')
+    d.stage1_blocks = int(s1['num_blocks'][0])
+    d.stage1_channels = int(s1['num_channels'][0])
+    for i, key in enumerate(('stage2', 'stage3', 'stage4')):
+        sc = cfg[key]
+        if sc['block_type'] != 'BASIC' or len(set(sc['num_blocks'])) != 1:
+            raise _lib.SncalError(f'{key}: BASIC blocks with a uniform block count are required')
+        d.num_modules[i] = int(sc['num_modules'])
+        d.num_branches[i] = int(sc['num_branches'])
+        d.num_blocks[i] = int(sc['num_blocks'][0])
+        for b, c in enumerate(sc['num_channels']):
+            d.num_channels[i][b] = int(c)
+    return d
+
+
+class HRNetHeatmap:
+    """Inference-only HRNet on the HIP engine.  ``dtype``: 'bf16' (fast path) or 'fp32' (parity path)."""
+
+    def __init__(self, hrnet_config, num_refinement_stages: int = 0, num_heatmaps: int = None,
+                 dtype: str = 'bf16', device='cuda:0'):
+        if num_refinement_stages != 0:
+            raise _lib.SncalError('refinement stages are never instantiated by the reference configs; unsupported')
+        self.cfg = load_config(hrnet_config)
+        self.dtype = DTYPES[dtype]
+        self.device = torch.device(device)
+        self._L = _lib.lib()
+        self._h = _lib.vp()
+        desc = _desc(self.cfg)
+        _lib.check(self._L.sncal_hrnet_create(ctypes.byref(desc), self.dtype, ctypes.byref(self._h)), 'sncal_hrnet_create')
+        self.num_classes = desc.num_classes
+        self._ws = None
+        self._loaded = False
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._L.sncal_hrnet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- weights --------------------------------------------------------------------------------
+    def conv_units(self):
+        """[(name, bn_name, cin, cout, k, stride, has_bias)] in the reference's registration order."""
+        out = []
+        name = ctypes.create_string_buffer(128)
+        bn = ctypes.create_string_buffer(128)
+        ci, co, k, s, hb = (ctypes.c_int() for _ in range(5))
+        for i in range(self._L.sncal_hrnet_num_convs(self._h)):
+            _lib.check(self._L.sncal_hrnet_conv_info(self._h, i, name, 128, bn, 128, ctypes.byref(ci), ctypes.byref(co),
+                                                     ctypes.byref(k), ctypes.byref(s), ctypes.byref(hb)), 'conv_info')
+            out.append((name.value.decode(), bn.value.decode(), ci.value, co.value, k.value, s.value, bool(hb.value)))
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference's nn_state_dict (keys 'model.conv1.weight', ... metamodel.py:108-124)."""
+        sd = {k.replace('_orig_mod.', ''): v for k, v in state_dict.items()}
+        used = set()
+        for i, (name, bn, cin, cout, k, stride, has_bias) in enumerate(self.conv_units()):
+            w = sd[name + '.weight'].detach().to('cpu', torch.float64)
+            used.add(name + '.weight')
+            if tuple(w.shape) != (cout, cin, k, k):
+                raise _lib.SncalError(f'{name}.weight has shape {tuple(w.shape)}, expected {(cout, cin, k, k)}')
+            b = torch.zeros(cout, dtype=torch.float64)
+            if has_bias:
+                b = sd[name + '.bias'].detach().to('cpu', torch.float64)
+                used.add(name + '.bias')
+            if bn:
+                g = sd[bn + '.weight'].detach().to('cpu', torch.float64)
+                beta = sd[bn + '.bias'].detach().to('cpu', torch.float64)
+                mu = sd[bn + '.running_mean'].detach().to('cpu', torch.float64)
+                var = sd[bn + '.running_var'].detach().to('cpu', torch.float64)
+                used.update({bn + s for s in ('.weight', '.bias', '.running_mean', '.running_var')})
+                scale = g / torch.sqrt(var + BN_EPS)
+                shift = beta + (b - mu) * scale
+            else:
+                scale = torch.ones(cout, dtype=torch.float64)
+                shift = b
+            wf = np.ascontiguousarray(w.to(torch.float32).numpy())
+            sc = np.ascontiguousarray(scale.to(torch.float32).numpy())
+            sh = np.ascontiguousarray(shift.to(torch.float32).numpy())
+            _lib.check(self._L.sncal_hrnet_set_conv(self._h, i, wf.ctypes.data, sc.ctypes.data, sh.ctypes.data), 'set_conv')
+        if strict:
+            extra = [k for k in sd if k not in used and not k.endswith('num_batches_tracked')]
+            if extra:
+                raise _lib.SncalError(f'unexpected keys in state dict: {extra[:5]}...')
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sncal_hrnet_finalize(self._h), 'sncal_hrnet_finalize')
+        self._loaded = True
+        return self
+
+    # ---- forward --------------------------------------------------------------------------------
+    def output_size(self, H, W):
+        h, w = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._L.sncal_hrnet_output_size(self._h, H, W, ctypes.byref(h), ctypes.byref(w)), 'output_size')
+        return h.value, w.value
+
+    def _workspace(self, B, H, W):
+        n = ctypes.c_size_t()
+        _lib.check(self._L.sncal_hrnet_workspace(self._h, B, H, W, ctypes.byref(n)), 'sncal_hrnet_workspace')
+        if self._ws is None or self._ws.numel() < n.value:
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, x: torch.Tensor, want_heat: bool = True, decode_size=None):
+        """x (B,3,H,W) fp32 on the GPU.  Returns (heat or None, kpts or None)."""
+        if not self._loaded:
+            raise _lib.SncalError('HRNetHeatmap: load_state_dict() has not been called')
+        _lib.require_device(x, torch.float32, 'x')
+        B, C, H, W = x.shape
+        if C != 3:
+            raise _lib.SncalError('x must have 3 channels')
+        h, w = self.output_size(H, W)
+        heat = torch.empty((B, self.num_classes, h, w), dtype=torch.float32, device=x.device) if want_heat else None
+        kpts = None
+        ih = iw = 0
+        if decode_size is not None:
+            ih, iw = int(decode_size[0]), int(decode_size[1])
+            kpts = torch.empty((B, self.num_classes - 1, 3), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = self._workspace(B, H, W)
+            _lib.check(self._L.sncal_hrnet_forward(self._h, x.data_ptr(), B, H, W,
+                                                   heat.data_ptr() if heat is not None else None,
+                                                   kpts.data_ptr() if kpts is not None else None, ih, iw,
+                                                   ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
+                       'sncal_hrnet_forward')
+        return heat, kpts
+
+    def __call__(self, x):
+        """Reference nn.Module contract: list of stage outputs, [-1] is the head output."""
+        return [self.forward(x, want_heat=True)[0]]
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise _lib.SncalError('weights live on the device given at construction')
+        return self

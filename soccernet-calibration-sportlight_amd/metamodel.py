@@ -1,0 +1,59 @@
+"""Model surface: ``load_model(path, device=...)`` -> object with ``.predict(x)``, ``.nn_module``, ``.device``.
+
+Mirrors argus.load_model + HRNetMetaModel.predict  (/root/reference/src/models/hrnet/metamodel.py:127-134,
+checkpoint schema :108-124; callers: /root/reference/src/utils/make_submit.py:51,68 and
+/root/reference/src/utils/export_line_result.py:168,181).  pytorch-argus itself is not a dependency: the
+checkpoint is the plain ``torch.save`` dict {'model_name', 'params', 'nn_state_dict'}.
+"""
+import torch
+
+from . import _lib
+from .hrnet import HRNetHeatmap
+from .transforms import HRNetPredictionTransform, EHMPredictionTransform
+
+
+class HRNetMetaModel:
+    """Inference-side mirror of the argus Model subclasses (keypoint: HRNetMetaModel, line: EHMMetaModel)."""
+    prediction_transform_cls = HRNetPredictionTransform
+
+    def __init__(self, params: dict, dtype: str = 'bf16'):
+        self.params = params
+        dev = params.get('device', 'cuda:0')
+        self.device = torch.device(dev[0] if isinstance(dev, (list, tuple)) else dev)
+        nn_params = dict(params['nn_module'])
+        self.nn_module = HRNetHeatmap(nn_params['hrnet_config'],
+                                      num_refinement_stages=nn_params.get('num_refinement_stages', 0),
+                                      num_heatmaps=nn_params.get('num_heatmaps'), dtype=dtype, device=self.device)
+        pt = params.get('prediction_transform', {})
+        self.prediction_transform = self.prediction_transform_cls(**pt) if pt else None
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B,3,H,W) float32 BGR in [0,1] (any device) -> prediction_transform(net(x)[-1]) on `device`."""
+        if self.prediction_transform is None:
+            raise _lib.SncalError('predict(): params hold no prediction_transform')
+        x = x.to(self.device, non_blocking=True)
+        pt = self.prediction_transform
+        if isinstance(pt, HRNetPredictionTransform):     # fused: decode straight from the engine
+            return self.nn_module.forward(x, want_heat=False, decode_size=(pt.H, pt.W))[1]
+        return pt(self.nn_module(x)[-1])
+
+    def eval(self):
+        return self
+
+
+class EHMMetaModel(HRNetMetaModel):
+    prediction_transform_cls = EHMPredictionTransform
+
+
+_MODELS = {'HRNetMetaModel': HRNetMetaModel, 'EHMMetaModel': EHMMetaModel}
+
+
+def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str = 'bf16', **_ignored):
+    """argus.load_model(path, loss=None, optimizer=None, device=...) for the two inference models."""
+    state = torch.load(file_path, map_location='cpu', weights_only=False)
+    params = dict(state['params'])
+    params['device'] = device
+    cls = _MODELS.get(state.get('model_name', 'HRNetMetaModel'), HRNetMetaModel)
+    model = cls(params, dtype=dtype)
+    model.nn_module.load_state_dict(state['nn_state_dict'])
+    return model

@@ -12,7 +12,7 @@
 //     DECODE  D1 keypoint decode (decode.hip)
 // Tensors get offsets inside one caller-provided workspace from a lifetime-based first-fit allocator, so a
 // forward is a fixed sequence of kernel launches with no allocation.  Frames are processed in sub-batches
-// (SNCAL_SUBBATCH, default 8) so that the activations of a sub-batch stay Infinity-Cache sized.
+// (SNCAL_SUBBATCH, default 32) so that the activations of a sub-batch stay Infinity-Cache sized.
 #include "common.hpp"
 #include "conv.hpp"
 #include "ops.hpp"
@@ -80,7 +80,7 @@ struct sncal_hrnet {
     std::vector<Tensor> tensors;
     int t_heat = -1, t_kpts_src = -1;
     bool finalized = false;
-    int subbatch = 8;
+    int subbatch = 32;
     const ConvVariant* variants = nullptr;
     int nvariants = 0;
     // cached per-(sb,H,W) layout
@@ -458,10 +458,9 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
             const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
             const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
             const long blocks = ty * tx * sb * L.nblk;
-            const double fill = std::min(1.0, (double)blocks / 512.0);        // keep >= 2 workgroups per CU busy
-            const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);
-            const double occ = lds <= 80 * 1024 ? 1.0 : 0.9;
-            const double score = eff * (0.5 + 0.5 * fill) * (0.6 + 0.4 * reuse / 2.4) * occ;
+            const double fill = std::min(1.0, (double)blocks / 256.0);        // at least one workgroup per CU
+            const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
+            const double score = eff * (0.3 + 0.7 * fill) * (0.4 + 0.6 * reuse / 2.4);
             if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; }
         }
     }

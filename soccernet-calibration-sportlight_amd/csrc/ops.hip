@@ -102,23 +102,46 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
     }
 }
 
+// One workgroup = 64 consecutive pixels x up to 64 channels.  Reads are row-contiguous (4 lanes x 64 B per
+// pixel), the channel reduction is thread-local + a 4-lane shuffle, and the NHWC->NCHW transpose goes
+// through LDS so that every store instruction writes 256 contiguous bytes of one channel plane.
 __global__ __launch_bounds__(256) void softmax_nchw_kernel(const float* __restrict__ logits, int cstride, int C,
                                                            size_t npix_total, size_t hw, int log_mode,
                                                            float* __restrict__ out) {
-    for (size_t p = blockIdx.x * 256ull + threadIdx.x; p < npix_total; p += (size_t)gridDim.x * 256) {
-        const float* row = logits + p * cstride;
-        float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
-        const size_t n = p / hw, r = p - n * hw;
-        float* o = out + n * C * hw + r;
-        if (log_mode) {
-            const float ls = logf(s);
-            for (int c = 0; c < C; ++c) o[(size_t)c * hw] = (row[c] - m) - ls;
-        } else {
-            const float inv = 1.0f / s;
-            for (int c = 0; c < C; ++c) o[(size_t)c * hw] = expf(row[c] - m) * inv;
+    __shared__ float s_t[64][65];
+    const int t = threadIdx.x, px = t >> 2, q = t & 3;
+    for (size_t p0 = (size_t)blockIdx.x * 64; p0 < npix_total; p0 += (size_t)gridDim.x * 64) {
+        const size_t p = p0 + px;
+        float v[16];
+        const bool live = p < npix_total;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            const int c = q * 16 + j * 4;
+            if (live && c < cstride) f = *reinterpret_cast<const float4*>(logits + p * cstride + c);
+            v[j * 4 + 0] = c + 0 < C ? f.x : -INFINITY; v[j * 4 + 1] = c + 1 < C ? f.y : -INFINITY;
+            v[j * 4 + 2] = c + 2 < C ? f.z : -INFINITY; v[j * 4 + 3] = c + 3 < C ? f.w : -INFINITY;
+        }
+        float m = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float e[16], ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { e[j] = (q * 16 + j < C) ? expf(v[j] - m) : 0.f; ssum += e[j]; }
+        ssum += __shfl_xor(ssum, 1, 64);
+        ssum += __shfl_xor(ssum, 2, 64);
+        const float ls = logf(ssum), inv = 1.0f / ssum;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s_t[q * 16 + j][px] = log_mode ? (v[j] - m) - ls : e[j] * inv;
+        __syncthreads();
+        const int lp = t & 63;
+        const size_t pp = p0 + lp;
+        if (pp < npix_total) {
+            const size_t n = pp / hw, r = pp - n * hw;
+            for (int c = t >> 6; c < C; c += 4) out[(n * C + c) * hw + r] = s_t[c][lp];
         }
     }
 }
@@ -151,8 +174,10 @@ int launch_upsample_add(int dtype, const UpsampleAddParams& p, hipStream_t s) {
 
 int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_total, size_t hw, int log_mode,
                         float* out, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_nchw_kernel, dim3(grid_for(npix_total)), dim3(256), 0, s, logits, cstride, C,
-                       npix_total, hw, log_mode, out);
+    if (C > 64 || cstride % 4 != 0) { set_error("softmax head supports at most 64 classes"); return SNCAL_ERR_ARG; }
+    const size_t groups = (npix_total + 63) / 64;
+    hipLaunchKernelGGL(softmax_nchw_kernel, dim3((unsigned)(groups > 16384 ? 16384 : groups)), dim3(256), 0, s, logits,
+                       cstride, C, npix_total, hw, log_mode, out);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

@@ -141,9 +141,9 @@ enum {                        /* sncal_camera.status                            
 typedef struct {              /* CameraCreator kwargs, make_submit.py:45-50                        */
     int algorithm;            /* 0 iterative_voter, 1 original_voter, 2 voter,
                                  3 opencv_calibration, 4 opencv_calibration_multiplane            */
-    float conf_thresh;
-    float conf_threshs[4];
     int n_conf_threshs;
+    double conf_thresh;       /* compared in double, like numpy's float32-scalar > python-float      */
+    double conf_threshs[4];
     double max_rmse, max_rmse_rel;
     int min_points, min_points_per_plane, min_points_for_refinement, reliable_thresh;
     double min_focal_length;

@@ -47,7 +47,8 @@ def project_point(position, rotation, fx, fy, pp, point3d):
         return np.zeros(3)
     rp = rp / rp[2]
     d = np.array([rp[0], rp[1]], dtype=np.float32)          # distort() returns float32 (:247)
-    return np.array([d[0] * fx + pp[0], d[1] * fy + pp[1], 1.0])
+    # float32 * np.float64 focal length (cv2 matrices are float64) -> float64 arithmetic from here on
+    return np.array([float(d[0]) * float(fx) + pp[0], float(d[1]) * float(fy) + pp[1], 1.0])
 
 
 def projection_rmse(position, rotation, fx, fy, pp, pts3d, pts2d):

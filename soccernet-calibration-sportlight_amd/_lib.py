@@ -34,8 +34,8 @@ class Camera(ctypes.Structure):
 
 class VoterCfg(ctypes.Structure):
     """sncal_voter_cfg."""
-    _fields_ = [('algorithm', ctypes.c_int), ('conf_thresh', ctypes.c_float),
-                ('conf_threshs', ctypes.c_float * 4), ('n_conf_threshs', ctypes.c_int),
+    _fields_ = [('algorithm', ctypes.c_int), ('n_conf_threshs', ctypes.c_int), ('conf_thresh', ctypes.c_double),
+                ('conf_threshs', ctypes.c_double * 4),
                 ('max_rmse', ctypes.c_double), ('max_rmse_rel', ctypes.c_double),
                 ('min_points', ctypes.c_int), ('min_points_per_plane', ctypes.c_int),
                 ('min_points_for_refinement', ctypes.c_int), ('reliable_thresh', ctypes.c_int),

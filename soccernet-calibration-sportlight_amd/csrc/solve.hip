@@ -1,0 +1,1165 @@
+// Batched camera solve on gfx950: one 64-lane wavefront per frame.
+//
+// Control flow follows the reference's CameraCreator (/root/reference/src/models/hrnet/prediction.py):
+//   __call__ :130-136, iterative_voter :245-257, voter :259-330, original_voter :339-437,
+//   get_camera_from_homography :487-520, get_camera_all_points :523-555 (+ quirks Q1/Q2),
+//   _reliable/_groundplane/_accurate_points :558-606, get_camera_gen :609-640, good_camera :469-484,
+//   opencv_calibration :138-170, opencv_calibration_multiplane :172-243,
+// and Camera.solve_pnp / refine_camera / projection_rmse / estimate_calibration_matrix_from_plane_homography
+// (/root/reference/baseline/camera.py:92-119, 270-277, 366-426).  The arithmetic behind the cv2 calls
+// (findHomography-RANSAC, solvePnPRansac, solvePnPRefineLM, calibrateCamera) is the build's own
+// restatement -- specification shared with oracle/solve.py, parity vs OpenCV itself is UNPINNED.
+//
+// Mapping to the hardware: lane i owns keypoint id i (57 template points <= 64 lanes; a line-intersection
+// candidate fills the slot of a missing keypoint with the same id, prediction.py:356-364).  A point subset
+// is a 64-bit lane mask.  Everything per point (residuals, Jacobian rows, inlier tests) is lane-parallel;
+// normal equations are assembled with butterfly wave reductions (every lane ends with bit-identical sums,
+// so all control flow stays wave-uniform); the small dense algebra (8x8 / 6x6 Cholesky, 3x3 adjugates,
+// polar iteration) runs redundantly in every lane's registers.  RANSAC hypotheses are lane-parallel too:
+// each lane draws its own 4-point sample with a counter-based hash and scores it against all points.
+// All arithmetic is fp64.  The solve is latency-bound (~1e5 FLOP per frame): it is reported in frames/s,
+// not as a roofline fraction, and runs on its own stream beside the MFMA-bound network.
+#include "common.hpp"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+constexpr int NPTS = 57;
+constexpr unsigned long long TOP_GATES_MASK = (1ull << 0) | (1ull << 1) | (1ull << 24) | (1ull << 25);
+constexpr unsigned long long ALL_MASK = (1ull << NPTS) - 1;
+constexpr unsigned long long GROUND_MASK = ALL_MASK & ~TOP_GATES_MASK;
+// prediction.py:20-21, 25-26
+constexpr unsigned long long GOAL_LEFT_MASK = (1ull << 0) | (1ull << 1) | (1ull << 2) | (1ull << 3) | (1ull << 6) |
+                                              (1ull << 7) | (1ull << 10) | (1ull << 11) | (1ull << 12) | (1ull << 13);
+constexpr unsigned long long GOAL_RIGHT_MASK = (1ull << 18) | (1ull << 19) | (1ull << 22) | (1ull << 23) | (1ull << 24) |
+                                               (1ull << 25) | (1ull << 26) | (1ull << 27) | (1ull << 28) | (1ull << 29);
+constexpr unsigned long long KEEP_MASK = ((1ull << 29) - 1) | (1ull << 40) | (1ull << 41) | (1ull << 42) | (1ull << 44) |
+                                         (1ull << 45) | (1ull << 48) | (1ull << 51) | (1ull << 52) | (1ull << 55);
+
+__constant__ double c_P64[NPTS * 3];
+__constant__ double c_P32[NPTS * 3];
+// order of ids inside the goal-plane id lists (for the duplication multiplicity, quirk Q1)
+__constant__ int c_goal_left_ids[10] = {0, 1, 2, 3, 6, 7, 10, 11, 12, 13};
+__constant__ int c_goal_right_ids[10] = {18, 19, 22, 23, 24, 25, 26, 27, 28, 29};
+
+typedef unsigned long long u64;
+
+// ---- wave helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
+__device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
+__device__ __forceinline__ int kth_set_bit(u64 m, int k) {
+    for (int i = 0; i < k; ++i) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+
+// ---- RANSAC sampler (shared spec: oracle/solve.py::_mix / sample4) -------------------------------------
+__device__ __forceinline__ u64 mix64(u64 h, u64 j) {
+    u64 z = h * 0x9E3779B97F4A7C15ull + j * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool sample4(int h, int n, int (&idx)[4]) {
+    int cnt = 0;
+    for (int j = 0; j < 16 && cnt < 4; ++j) {
+        const int c = (int)((mix64((u64)h, (u64)j) >> 32) % (u64)n);
+        bool dup = false;
+        for (int k = 0; k < cnt; ++k) dup |= idx[k] == c;
+        if (!dup) idx[cnt++] = c;
+    }
+    return cnt == 4;
+}
+
+// ---- small dense algebra (register resident, fully unrolled) -------------------------------------------
+__device__ __forceinline__ double det3(const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+__device__ __forceinline__ void adj3(const double* m, double* a) {   // adjugate: inv = adj / det
+    a[0] = m[4] * m[8] - m[5] * m[7]; a[1] = m[2] * m[7] - m[1] * m[8]; a[2] = m[1] * m[5] - m[2] * m[4];
+    a[3] = m[5] * m[6] - m[3] * m[8]; a[4] = m[0] * m[8] - m[2] * m[6]; a[5] = m[2] * m[3] - m[0] * m[5];
+    a[6] = m[3] * m[7] - m[4] * m[6]; a[7] = m[1] * m[6] - m[0] * m[7]; a[8] = m[0] * m[4] - m[1] * m[3];
+}
+__device__ __forceinline__ void mul33(const double* a, const double* b, double* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+__device__ __forceinline__ void mul3v(const double* a, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a[i * 3] * v[0] + a[i * 3 + 1] * v[1] + a[i * 3 + 2] * v[2];
+}
+
+// SPD solve by Cholesky on a packed-full NxN matrix; false when a pivot <= rel_tol * max diag
+template <int N>
+__device__ __forceinline__ bool chol_solve(const double (&A)[N][N], const double (&b)[N], double (&x)[N]) {
+    double L[N][N];
+    double dmax = A[0][0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) dmax = fmax(dmax, A[i][i]);
+    if (!(dmax > 0)) return false;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 1e-11 * dmax)) { ok = false; d = 1.0; }
+        const double ljj = sqrt(d);
+        L[j][j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s / ljj;
+        }
+    }
+    if (!ok) return false;
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+    return true;
+}
+
+__device__ __forceinline__ void polar3(double* R) {   // nearest rotation by Newton iteration
+    if (det3(R) < 0) { R[2] = -R[2]; R[5] = -R[5]; R[8] = -R[8]; }
+    for (int it = 0; it < 12; ++it) {
+        double a[9];
+        adj3(R, a);
+        const double d = det3(R);
+        // inv(R)^T = adj^T / det
+        const double n[9] = {a[0] / d, a[3] / d, a[6] / d, a[1] / d, a[4] / d, a[7] / d, a[2] / d, a[5] / d, a[8] / d};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = 0.5 * (R[i] + n[i]);
+    }
+}
+
+__device__ __forceinline__ void exp_so3(const double* w, double* E) {
+    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    mul33(K, K, K2);
+    double a, b;
+    if (th < 1e-8) { a = 1.0; b = 0.5; }
+    else { a = sin(th) / th; b = (1 - cos(th)) / (th * th); }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + b * K2[i];
+}
+
+// ---- homography ----------------------------------------------------------------------------------
+__device__ __forceinline__ bool basis_map(const double (&p)[4][2], double* out) {
+    const double M[9] = {p[0][0], p[1][0], p[2][0], p[0][1], p[1][1], p[2][1], 1.0, 1.0, 1.0};
+    const double det = det3(M);
+    double mx = 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = fmax(mx, fmax(fabs(p[i][0]), fabs(p[i][1])));
+    if (fabs(det) < 1e-9 * mx * mx) return false;
+    double a[9];
+    adj3(M, a);
+    const double rhs[3] = {p[3][0], p[3][1], 1.0};
+    double lam[3];
+    mul3v(a, rhs, lam);
+    lam[0] /= det; lam[1] /= det; lam[2] /= det;
+    if (fmin(fabs(lam[0]), fmin(fabs(lam[1]), fabs(lam[2]))) < 1e-9) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[i * 3 + j] = M[i * 3 + j] * lam[j];
+    return true;
+}
+
+__device__ __forceinline__ bool homography_4pt(const double (&s)[4][2], const double (&d)[4][2], double* H) {
+    double A[9], B[9];
+    if (!basis_map(s, A) || !basis_map(d, B)) return false;
+    const double detA = det3(A);
+    if (fabs(detA) < 1e-300) return false;
+    double adjA[9];
+    adj3(A, adjA);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) adjA[i] /= detA;
+    mul33(B, adjA, H);
+    if (fabs(H[8]) < 1e-12) return false;
+    const double s8 = H[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] /= s8;
+    return true;
+}
+
+__device__ __forceinline__ void apply_h(const double* H, double x, double y, double& u, double& v) {
+    double w = H[6] * x + H[7] * y + H[8];
+    if (fabs(w) < 1e-300) w = 1e-300;
+    u = (H[0] * x + H[1] * y + H[2]) / w;
+    v = (H[3] * x + H[4] * y + H[5]) / w;
+}
+
+// normalised least squares (h33 = 1) + `iters` damped Gauss-Newton steps on the reprojection error
+__device__ bool homography_lsq(u64 mask, double sx, double sy, double du, double dv, int iters, double* H) {
+    const int lane = threadIdx.x & 63;
+    const bool in = (mask >> lane) & 1;
+    const double n = (double)popc64(mask);
+    const double csx = wsum(in ? sx : 0.0) / n, csy = wsum(in ? sy : 0.0) / n;
+    const double cdx = wsum(in ? du : 0.0) / n, cdy = wsum(in ? dv : 0.0) / n;
+    const double ms = wsum(in ? sqrt((sx - csx) * (sx - csx) + (sy - csy) * (sy - csy)) : 0.0) / n;
+    const double md = wsum(in ? sqrt((du - cdx) * (du - cdx) + (dv - cdy) * (dv - cdy)) : 0.0) / n;
+    const double ss = sqrt(2.0) / fmax(ms, 1e-12), sd = sqrt(2.0) / fmax(md, 1e-12);
+    const double x = (sx - csx) * ss, y = (sy - csy) * ss, u = (du - cdx) * sd, v = (dv - cdy) * sd;
+    double A[8][8], b[8], h[8];
+    {
+        const double ru[8] = {x, y, 1, 0, 0, 0, -u * x, -u * y};
+        const double rv[8] = {0, 0, 0, x, y, 1, -v * x, -v * y};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = i; j < 8; ++j) {
+                const double s = wsum(in ? ru[i] * ru[j] + rv[i] * rv[j] : 0.0);
+                A[i][j] = s; A[j][i] = s;
+            }
+            b[i] = wsum(in ? ru[i] * u + rv[i] * v : 0.0);
+        }
+    }
+    if (!chol_solve<8>(A, b, h)) return false;
+    auto cost = [&](const double* hh) {
+        double w = hh[6] * x + hh[7] * y + 1.0;
+        if (fabs(w) < 1e-300) w = 1e-300;
+        const double pu = (hh[0] * x + hh[1] * y + hh[2]) / w - u, pv = (hh[3] * x + hh[4] * y + hh[5]) / w - v;
+        return wsum(in ? pu * pu + pv * pv : 0.0);
+    };
+    double lam = 1e-3;
+    double c0 = cost(h);
+    for (int it = 0; it < iters; ++it) {
+        const double w = h[6] * x + h[7] * y + 1.0;
+        const double pu = (h[0] * x + h[1] * y + h[2]) / w, pv = (h[3] * x + h[4] * y + h[5]) / w;
+        const double ju[8] = {x / w, y / w, 1 / w, 0, 0, 0, -pu * x / w, -pu * y / w};
+        const double jv[8] = {0, 0, 0, x / w, y / w, 1 / w, -pv * x / w, -pv * y / w};
+        const double eu = pu - u, ev = pv - v;
+        double g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = i; j < 8; ++j) {
+                const double s = wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                A[i][j] = s; A[j][i] = s;
+            }
+            g[i] = -wsum(in ? ju[i] * eu + jv[i] * ev : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i][i] += lam * A[i][i];
+        double step[8], hn[8];
+        double c1 = INFINITY;
+        if (chol_solve<8>(A, g, step)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hn[i] = h[i] + step[i];
+            c1 = cost(hn);
+        }
+        if (c1 < c0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = hn[i];
+            c0 = c1;
+            lam = fmax(lam * 0.1, 1e-12);
+        } else {
+            lam *= 10.0;
+        }
+    }
+    // H = Td^-1 * Hn * Ts
+    const double Hn[9] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0};
+    const double Ts[9] = {ss, 0, -ss * csx, 0, ss, -ss * csy, 0, 0, 1};
+    const double Ti[9] = {1 / sd, 0, cdx, 0, 1 / sd, cdy, 0, 0, 1};
+    double t1[9];
+    mul33(Hn, Ts, t1);
+    mul33(Ti, t1, H);
+    if (fabs(H[8]) < 1e-300) return false;
+    const double s8 = H[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] /= s8;
+    return true;
+}
+
+struct Best { int cnt; double s; int h; };
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {   // is a better than b
+    return a.cnt > b.cnt || (a.cnt == b.cnt && (a.s < b.s || (a.s == b.s && a.h < b.h)));
+}
+__device__ __forceinline__ Best wave_best(Best v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best q;
+        q.cnt = __shfl_xor(v.cnt, o, 64); q.s = __shfl_xor(v.s, o, 64); q.h = __shfl_xor(v.h, o, 64);
+        if (better(q, v)) v = q;
+    }
+    return v;
+}
+
+// cv2.findHomography(src, dst, RANSAC, thr) restated (ellipse.py:496-498)
+__device__ bool homography_ransac(u64 mask, double sx, double sy, double du, double dv, double thr, double* H) {
+    const int lane = threadIdx.x & 63;
+    const int n = popc64(mask);
+    if (n < 4) return false;
+    Best mine{-1, INFINITY, 1 << 30};
+    double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int round = 0; round < 2; ++round) {
+        const int h = round * 64 + lane;
+        int idx[4] = {0, 0, 0, 0};
+        bool ok = sample4(h, n, idx);
+        double s[4][2], d[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int src = kth_set_bit(mask, idx[k]);
+            s[k][0] = __shfl(sx, src, 64); s[k][1] = __shfl(sy, src, 64);
+            d[k][0] = __shfl(du, src, 64); d[k][1] = __shfl(dv, src, 64);
+        }
+        double Hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // never read uninitialised (a failed hypothesis keeps zeros)
+        ok = ok && homography_4pt(s, d, Hh);
+        int cnt = 0;
+        double se = 0;
+        for (u64 m = mask; m; m &= m - 1) {
+            const int j = __ffsll((long long)m) - 1;
+            const double x = bcast(sx, j), y = bcast(sy, j), u = bcast(du, j), v = bcast(dv, j);
+            if (ok) {
+                double pu, pv;
+                apply_h(Hh, x, y, pu, pv);
+                const double e2 = (pu - u) * (pu - u) + (pv - v) * (pv - v);
+                if (e2 <= thr * thr) { ++cnt; se += e2; }
+            }
+        }
+        const Best cand{ok ? cnt : -1, ok ? se : INFINITY, h};
+        const bool take = ok && better(cand, mine);
+        mine.cnt = take ? cand.cnt : mine.cnt; mine.s = take ? cand.s : mine.s; mine.h = take ? cand.h : mine.h;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Hm[i] = take ? Hh[i] : Hm[i];
+    }
+    const Best best = wave_best(mine);
+    if (best.cnt < 4) return false;
+    const int owner = best.h & 63;
+    double Hb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hb[i] = bcast(Hm[i], owner);
+    double pu, pv;
+    apply_h(Hb, sx, sy, pu, pv);
+    const double e2 = (pu - du) * (pu - du) + (pv - dv) * (pv - dv);
+    const u64 inl = __ballot(((mask >> lane) & 1) && e2 <= thr * thr);
+    return homography_lsq(inl, sx, sy, du, dv, 10, H);
+}
+
+// camera.py:366-426 in closed form: w = (a,0,a,b,(cy/cx)b,c) spans the null space of the 5x6 system
+__device__ bool k_from_homography(const double* H, double cx, double cy, double& fx, double& fy) {
+    const double k = cy / cx;
+    const double r3[3] = {H[0] * H[1] + H[3] * H[4], (H[0] * H[7] + H[1] * H[6]) + k * (H[3] * H[7] + H[4] * H[6]), H[6] * H[7]};
+    const double r4[3] = {(H[0] * H[0] - H[1] * H[1]) + (H[3] * H[3] - H[4] * H[4]),
+                          (2 * H[0] * H[6] - 2 * H[1] * H[7]) + k * (2 * H[3] * H[6] - 2 * H[4] * H[7]),
+                          H[6] * H[6] - H[7] * H[7]};
+    const double a = r3[1] * r4[2] - r3[2] * r4[1], b = r3[2] * r4[0] - r3[0] * r4[2], c = r3[0] * r4[1] - r3[1] * r4[0];
+    if (c == 0) return false;
+    const double W00 = a / c, W02 = b / c, W12 = k * b / c;
+    if (!(W00 > 0)) return false;
+    const double L00 = sqrt(W00), L20 = W02 / L00, L21 = W12 / L00;   // W11 == W00
+    const double d = 1.0 - L20 * L20 - L21 * L21;
+    if (!(d > 0)) return false;
+    const double L22 = sqrt(d);
+    fx = L22 / L00; fy = L22 / L00;
+    return true;
+}
+
+// ---- pose ----------------------------------------------------------------------------------------
+__device__ bool pose_from_homography(const double* H, double fx, double fy, double cx, double cy, double* R, double* t) {
+    const double Ki[9] = {1 / fx, 0, -cx / fx, 0, 1 / fy, -cy / fy, 0, 0, 1};
+    double hp[9];
+    mul33(Ki, H, hp);
+    const double n0 = sqrt(hp[0] * hp[0] + hp[3] * hp[3] + hp[6] * hp[6]);
+    const double n1 = sqrt(hp[1] * hp[1] + hp[4] * hp[4] + hp[7] * hp[7]);
+    if (n0 < 1e-300 || n1 < 1e-300) return false;
+    const double l1 = 1 / n0, l2 = 1 / n1, l3 = sqrt(l1 * l2);
+    double r0[3] = {hp[0] * l1, hp[3] * l1, hp[6] * l1}, r1[3] = {hp[1] * l2, hp[4] * l2, hp[7] * l2};
+    t[0] = hp[2] * l3; t[1] = hp[5] * l3; t[2] = hp[8] * l3;
+    if (t[2] < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { r0[i] = -r0[i]; r1[i] = -r1[i]; t[i] = -t[i]; }
+    }
+    const double r2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    R[0] = r0[0]; R[1] = r1[0]; R[2] = r2[0];
+    R[3] = r0[1]; R[4] = r1[1]; R[5] = r2[1];
+    R[6] = r0[2]; R[7] = r1[2]; R[8] = r2[2];
+    polar3(R);
+    return true;
+}
+
+struct K4 { double fx, fy, cx, cy; };
+
+__device__ __forceinline__ void cam_point(const double* R, const double* t, const double* X, double* Xc) {
+    Xc[0] = X[0] * R[0] + X[1] * R[1] + X[2] * R[2] + t[0];
+    Xc[1] = X[0] * R[3] + X[1] * R[4] + X[2] * R[5] + t[1];
+    Xc[2] = X[0] * R[6] + X[1] * R[7] + X[2] * R[8] + t[2];
+}
+__device__ __forceinline__ double reproj_e2(const double* R, const double* t, const K4& k, const double* X, double u,
+                                            double v, double* zout) {
+    double Xc[3];
+    cam_point(R, t, X, Xc);
+    *zout = Xc[2];
+    const double zs = fabs(Xc[2]) < 1e-12 ? 1e-12 : Xc[2];
+    const double pu = k.fx * Xc[0] / zs + k.cx - u, pv = k.fy * Xc[1] / zs + k.cy - v;
+    return pu * pu + pv * pv;
+}
+
+// pose rows: residual + Jacobian wrt (w, t) for the left perturbation R <- exp(w) R
+__device__ __forceinline__ void pose_rows(const double* R, const double* t, double f_x, double f_y, double cx, double cy,
+                                          const double* X, double u, double v, double (&ju)[6], double (&jv)[6],
+                                          double& ru, double& rv, double& xn, double& yn) {
+    double Xc[3];
+    cam_point(R, t, X, Xc);
+    const double z = fabs(Xc[2]) < 1e-12 ? 1e-12 : Xc[2];
+    const double x = Xc[0] / z, y = Xc[1] / z;
+    xn = x; yn = y;
+    ru = f_x * x + cx - u; rv = f_y * y + cy - v;
+    const double du[3] = {f_x / z, 0.0, -f_x * x / z}, dv[3] = {0.0, f_y / z, -f_y * y / z};
+    ju[0] = du[2] * Xc[1] - du[1] * Xc[2]; ju[1] = du[0] * Xc[2] - du[2] * Xc[0]; ju[2] = du[1] * Xc[0] - du[0] * Xc[1];
+    ju[3] = du[0]; ju[4] = du[1]; ju[5] = du[2];
+    jv[0] = dv[2] * Xc[1] - dv[1] * Xc[2]; jv[1] = dv[0] * Xc[2] - dv[2] * Xc[0]; jv[2] = dv[1] * Xc[0] - dv[0] * Xc[1];
+    jv[3] = dv[0]; jv[4] = dv[1]; jv[5] = dv[2];
+}
+
+__device__ __forceinline__ void apply_step(const double* R, const double* t, const double* step, double* Rn, double* tn) {
+    double E[9];
+    exp_so3(step, E);
+    mul33(E, R, Rn);
+    mul3v(E, t, tn);
+    tn[0] += step[3]; tn[1] += step[4]; tn[2] += step[5];
+}
+
+// Camera.refine_camera (camera.py:105-119): LM over the pose, K fixed, to convergence
+__device__ void refine_pose_lm(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v,
+                               int max_iters, double eps) {
+    const int lane = threadIdx.x & 63;
+    const bool in = (mask >> lane) & 1;
+    auto cost = [&](const double* R_, const double* t_) {
+        double z;
+        const double e2 = reproj_e2(R_, t_, k, X, u, v, &z);
+        return wsum(in ? e2 : 0.0);
+    };
+    double lam = 1e-3;
+    double c0 = cost(R, t);
+    for (int it = 0; it < max_iters; ++it) {
+        double ju[6], jv[6], ru, rv, xn, yn;
+        pose_rows(R, t, k.fx, k.fy, k.cx, k.cy, X, u, v, ju, jv, ru, rv, xn, yn);
+        double A[6][6], g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                const double s = wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                A[i][j] = s; A[j][i] = s;
+            }
+            g[i] = -wsum(in ? ju[i] * ru + jv[i] * rv : 0.0);
+        }
+        bool improved = false;
+        double step[6], dc = 0;
+        for (int tr = 0; tr < 12; ++tr) {
+            double Ad[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Ad[i][j] = A[i][j] + (i == j ? A[i][i] * lam : 0.0);
+            if (!chol_solve<6>(Ad, g, step)) { lam *= 10; continue; }
+            double Rn[9], tn[3];
+            apply_step(R, t, step, Rn, tn);
+            const double c1 = cost(Rn, tn);
+            if (c1 < c0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+                t[0] = tn[0]; t[1] = tn[1]; t[2] = tn[2];
+                lam = fmax(lam * 0.1, 1e-15);
+                dc = c0 - c1; c0 = c1; improved = true;
+                break;
+            }
+            lam *= 10;
+        }
+        double smax = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) smax = fmax(smax, fabs(step[i]));
+        if (!improved || smax < eps || dc <= 1e-16 * fmax(c0, 1e-30)) break;
+    }
+    polar3(R);
+}
+
+// Camera.solve_pnp (camera.py:92-103): planar minimal solver on ground points + 8 px inliers + LM refit
+__device__ bool pnp_ransac(u64 mask, const K4& k, const double* X, double u, double v, double* R, double* t) {
+    const int lane = threadIdx.x & 63;
+    const u64 gmask = mask & GROUND_MASK;
+    const int n = popc64(gmask);
+    if (n < 4) return false;
+    int idx[4] = {0, 0, 0, 0};
+    bool ok = sample4(lane, n, idx);
+    double s[4][2], d[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int src = kth_set_bit(gmask, idx[q]);
+        s[q][0] = __shfl(X[0], src, 64); s[q][1] = __shfl(X[1], src, 64);
+        d[q][0] = __shfl(u, src, 64); d[q][1] = __shfl(v, src, 64);
+    }
+    double Hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Rh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, th[3] = {0, 0, 1};
+    ok = ok && homography_4pt(s, d, Hh);
+    ok = ok && pose_from_homography(Hh, k.fx, k.fy, k.cx, k.cy, Rh, th);
+    int cnt = 0;
+    double se = 0;
+    for (u64 m = mask; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const double Xj[3] = {bcast(X[0], j), bcast(X[1], j), bcast(X[2], j)};
+        const double uj = bcast(u, j), vj = bcast(v, j);
+        if (ok) {
+            double z;
+            const double e2 = reproj_e2(Rh, th, k, Xj, uj, vj, &z);
+            if (e2 <= 64.0 && z > 1e-9) { ++cnt; se += e2; }
+        }
+    }
+    const Best best = wave_best(Best{ok ? cnt : -1, ok ? se : INFINITY, lane});
+    if (best.cnt < 4) return false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = bcast(Rh[i], best.h);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = bcast(th[i], best.h);
+    double z;
+    const double e2 = reproj_e2(R, t, k, X, u, v, &z);
+    const u64 inl = __ballot(((mask >> lane) & 1) && e2 <= 64.0 && z > 1e-9);
+    refine_pose_lm(inl, R, t, k, X, u, v, 20, 1e-10);
+    return true;
+}
+
+// ---- calibrateCamera restatement (planar views, pp fixed at ((w-1)/2,(h-1)/2), aspect 1, no distortion) ----
+struct View { u64 mask; int kind; double weight; };   // kind 0 ground (x,y), 1 goal plane (y,z)
+
+__device__ bool calibrate_planes(const View* views, int nviews, const double* X32, double u32, double v32, int img_w,
+                                 int img_h, double& f_out, double* R0, double* t0) {
+    const int lane = threadIdx.x & 63;
+    const double cx = (img_w - 1) * 0.5, cy = (img_h - 1) * 0.5;
+    double Hs[3][9];
+    double n00 = 0, n01 = 0, n11 = 0, r0 = 0, r1 = 0;
+    for (int vi = 0; vi < nviews; ++vi) {
+        const double px = views[vi].kind ? X32[1] : X32[0], py = views[vi].kind ? X32[2] : X32[1];
+        if (!homography_lsq(views[vi].mask, px, py, u32, v32, 10, Hs[vi])) return false;
+        double Hc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Hc[i] = Hs[vi][i];
+        Hc[0] -= Hc[6] * cx; Hc[1] -= Hc[7] * cx; Hc[2] -= Hc[8] * cx;
+        Hc[3] -= Hc[6] * cy; Hc[4] -= Hc[7] * cy; Hc[5] -= Hc[8] * cy;
+        double h[3] = {Hc[0], Hc[3], Hc[6]}, v[3] = {Hc[1], Hc[4], Hc[7]}, d1[3], d2[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { d1[i] = (h[i] + v[i]) * 0.5; d2[i] = (h[i] - v[i]) * 0.5; }
+        auto nrm = [](double* a) {
+            const double n = fmax(sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-300);
+            a[0] /= n; a[1] /= n; a[2] /= n;
+        };
+        nrm(h); nrm(v); nrm(d1); nrm(d2);
+        const double sw = sqrt(views[vi].weight);
+        const double a0[2] = {sw * (h[0] * v[0]), sw * (h[1] * v[1])}, b0 = -sw * h[2] * v[2];
+        const double a1[2] = {sw * (d1[0] * d2[0]), sw * (d1[1] * d2[1])}, b1 = -sw * d1[2] * d2[2];
+        n00 += a0[0] * a0[0] + a1[0] * a1[0]; n01 += a0[0] * a0[1] + a1[0] * a1[1]; n11 += a0[1] * a0[1] + a1[1] * a1[1];
+        r0 += a0[0] * b0 + a1[0] * b1; r1 += a0[1] * b0 + a1[1] * b1;
+    }
+    const double det = n00 * n11 - n01 * n01;
+    if (!(fabs(det) > 1e-14 * fmax(n00 * n11, 1e-300))) return false;
+    const double s0 = (n11 * r0 - n01 * r1) / det, s1 = (n00 * r1 - n01 * r0) / det;
+    if (s0 == 0 || s1 == 0) return false;
+    double f = 0.5 * (sqrt(fabs(1.0 / s0)) + sqrt(fabs(1.0 / s1)));
+    if (!isfinite(f) || f <= 0) return false;
+    double Rv[3][9], tv[3][3];
+    for (int vi = 0; vi < nviews; ++vi) {
+        if (!pose_from_homography(Hs[vi], f, f, cx, cy, Rv[vi], tv[vi])) return false;
+        const double Xp[3] = {views[vi].kind ? X32[1] : X32[0], views[vi].kind ? X32[2] : X32[1], 0.0};
+        const K4 k{f, f, cx, cy};
+        refine_pose_lm(views[vi].mask, Rv[vi], tv[vi], k, Xp, u32, v32, 20, 1e-10);
+    }
+    auto total_cost = [&](double f_, double (*Rs)[9], double (*ts)[3]) {
+        double c = 0;
+        for (int vi = 0; vi < nviews; ++vi) {
+            const double Xp[3] = {views[vi].kind ? X32[1] : X32[0], views[vi].kind ? X32[2] : X32[1], 0.0};
+            const K4 k{f_, f_, cx, cy};
+            double z;
+            const double e2 = reproj_e2(Rs[vi], ts[vi], k, Xp, u32, v32, &z);
+            c += views[vi].weight * wsum(((views[vi].mask >> lane) & 1) ? e2 : 0.0);
+        }
+        return c;
+    };
+    double lam = 1e-3;
+    double c0 = total_cost(f, Rv, tv);
+    for (int it = 0; it < 60; ++it) {
+        double A[3][6][6], Bv[3][6], g[3][6];
+        double aff = 0, gf = 0;
+        for (int vi = 0; vi < nviews; ++vi) {
+            const bool in = (views[vi].mask >> lane) & 1;
+            const double Xp[3] = {views[vi].kind ? X32[1] : X32[0], views[vi].kind ? X32[2] : X32[1], 0.0};
+            double ju[6], jv[6], ru, rv, xn, yn;
+            pose_rows(Rv[vi], tv[vi], f, f, cx, cy, Xp, u32, v32, ju, jv, ru, rv, xn, yn);
+            const double wgt = views[vi].weight;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = i; j < 6; ++j) {
+                    const double s = wgt * wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                    A[vi][i][j] = s; A[vi][j][i] = s;
+                }
+                Bv[vi][i] = wgt * wsum(in ? ju[i] * xn + jv[i] * yn : 0.0);
+                g[vi][i] = wgt * wsum(in ? ju[i] * ru + jv[i] * rv : 0.0);
+            }
+            aff += wgt * wsum(in ? xn * xn + yn * yn : 0.0);
+            gf += wgt * wsum(in ? xn * ru + yn * rv : 0.0);
+        }
+        bool improved = false;
+        double dc = 0;
+        for (int tr = 0; tr < 12; ++tr) {
+            double s_aff = aff * (1 + lam), s_g = gf;
+            double AiB[3][6], Aig[3][6];
+            bool ok = true;
+            for (int vi = 0; vi < nviews && ok; ++vi) {
+                double Ad[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) Ad[i][j] = A[vi][i][j] + (i == j ? lam * A[vi][i][i] : 0.0);
+                ok = chol_solve<6>(Ad, Bv[vi], AiB[vi]) && chol_solve<6>(Ad, g[vi], Aig[vi]);
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { s_aff -= Bv[vi][i] * AiB[vi][i]; s_g -= Bv[vi][i] * Aig[vi][i]; }
+                }
+            }
+            if (!ok || fabs(s_aff) < 1e-300) { lam *= 10; continue; }
+            const double df = -s_g / s_aff;
+            double Rn[3][9], tn[3][3];
+            for (int vi = 0; vi < nviews; ++vi) {
+                double step[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) step[i] = -(Aig[vi][i] + AiB[vi][i] * df);
+                apply_step(Rv[vi], tv[vi], step, Rn[vi], tn[vi]);
+            }
+            const double fn = f + df;
+            const double c1 = fn > 0 ? total_cost(fn, Rn, tn) : INFINITY;
+            if (c1 < c0) {
+                dc = c0 - c1; c0 = c1; f = fn;
+                for (int vi = 0; vi < nviews; ++vi) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rv[vi][i] = Rn[vi][i];
+                    tv[vi][0] = tn[vi][0]; tv[vi][1] = tn[vi][1]; tv[vi][2] = tn[vi][2];
+                }
+                lam = fmax(lam * 0.1, 1e-15);
+                improved = true;
+                break;
+            }
+            lam *= 10;
+        }
+        if (!improved || dc <= 1e-16 * fmax(c0, 1e-30)) break;
+    }
+    f_out = f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = Rv[0][i];
+    polar3(R0);
+    t0[0] = tv[0][0]; t0[1] = tv[0][1]; t0[2] = tv[0][2];
+    return true;
+}
+
+// ---- camera record + reference control flow ----------------------------------------------------------
+struct Cam {
+    double R[9], pos[3];
+    double fx, fy, cx, cy;      // calibration matrix (cx,cy as left by calibrateCamera: quirk Q3)
+    double ppx, ppy;            // principal_point used by project_point / JSON
+    double rmse;
+    int tag;
+};
+
+__device__ __forceinline__ void cam_set_pose(Cam& c, const double* R, const double* t) {   // position = -R^T t
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = R[i];
+    c.pos[0] = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]);
+    c.pos[1] = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]);
+    c.pos[2] = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+}
+__device__ __forceinline__ void cam_t(const Cam& c, double* t) {   // t = -R pos
+    t[0] = -(c.R[0] * c.pos[0] + c.R[1] * c.pos[1] + c.R[2] * c.pos[2]);
+    t[1] = -(c.R[3] * c.pos[0] + c.R[4] * c.pos[1] + c.R[5] * c.pos[2]);
+    t[2] = -(c.R[6] * c.pos[0] + c.R[7] * c.pos[1] + c.R[8] * c.pos[2]);
+}
+
+struct Pts {   // lane-local point data
+    double X64[3], X32[3];
+    double u, v, u32, v32;
+};
+
+__device__ bool cam_solve_pnp(Cam& c, u64 mask, const Pts& p) {
+    double R[9], t[3];
+    const K4 k{c.fx, c.fy, c.cx, c.cy};
+    if (!pnp_ransac(mask, k, p.X64, p.u, p.v, R, t)) return false;
+    cam_set_pose(c, R, t);
+    return true;
+}
+__device__ void cam_refine(Cam& c, u64 mask, const Pts& p) {
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = c.R[i];
+    cam_t(c, t);
+    const K4 k{c.fx, c.fy, c.cx, c.cy};
+    refine_pose_lm(mask, R, t, k, p.X64, p.u, p.v, 100, 1e-10);
+    cam_set_pose(c, R, t);
+}
+// Camera.projection_rmse (camera.py:270-277; project_point :249-268 with the fp32 round trip of distort :247)
+__device__ double cam_rmse(const Cam& c, u64 mask, const Pts& p) {
+    const int lane = threadIdx.x & 63;
+    const double d[3] = {p.X64[0] - c.pos[0], p.X64[1] - c.pos[1], p.X64[2] - c.pos[2]};
+    double r[3];
+    mul3v(c.R, d, r);
+    double px = 0, py = 0;
+    if (!(r[2] <= 1e-3)) {
+        const float xn = (float)(r[0] / r[2]), yn = (float)(r[1] / r[2]);
+        px = (double)xn * c.fx + c.ppx;
+        py = (double)yn * c.fy + c.ppy;
+    }
+    const double l2 = sqrt((p.u - px) * (p.u - px) + (p.v - py) * (p.v - py));
+    return wsum(((mask >> lane) & 1) ? l2 : 0.0) / (double)popc64(mask);
+}
+__device__ __forceinline__ bool good_camera(const Cam& c) {   // prediction.py:469-484
+    return c.fx >= 10 && c.fx <= 20000 && c.pos[0] > -250 && c.pos[0] < 250 && c.pos[1] > -250 && c.pos[1] < 250 &&
+           c.pos[2] > -100 && c.pos[2] < 0;
+}
+
+__device__ int build_views(u64 mask, int min_pts, bool duplicate, View* views) {
+    int nv = 0;
+    const u64 pm[3] = {mask & GROUND_MASK, mask & GOAL_LEFT_MASK, mask & GOAL_RIGHT_MASK};
+    for (int pl = 0; pl < 3; ++pl) {
+        if (!pm[pl]) continue;
+        double mult = 1.0;
+        if (duplicate) {   // quirk Q1: the list object is appended once per id from the first detected one on
+            int first = 0, len = 0;
+            if (pl == 0) {
+                len = 54;                                            // range(58) minus the 4 crossbar ids (Q6)
+                const int id = __ffsll((long long)pm[0]) - 1;
+                first = id - popc64(TOP_GATES_MASK & ((1ull << id) - 1));
+            } else {
+                len = 10;
+                const int* ids = pl == 1 ? c_goal_left_ids : c_goal_right_ids;
+                first = 10;
+                for (int q = 9; q >= 0; --q) if ((pm[pl] >> ids[q]) & 1) first = q;
+            }
+            mult = (double)(len - first);
+        }
+        if (popc64(pm[pl]) >= min_pts) { views[nv].mask = pm[pl]; views[nv].kind = pl == 0 ? 0 : 1; views[nv].weight = mult; ++nv; }
+    }
+    return nv;
+}
+
+__device__ void cam_from_calibration(Cam& c, double f, const double* R0, const double* t0, int img_w, int img_h) {
+    c.fx = c.fy = f;
+    c.cx = (img_w - 1) * 0.5; c.cy = (img_h - 1) * 0.5;
+    c.ppx = img_w / 2.0; c.ppy = img_h / 2.0;
+    cam_set_pose(c, R0, t0);
+}
+
+enum { ST_OK = 0, ST_NONE = 1, ST_RAISE = 2 };   // value / None / exception
+
+// prediction.py:487-520
+__device__ int camera_from_homography(u64 mask, const Pts& p, int img_w, int img_h, Cam& c) {
+    const u64 g = mask & GROUND_MASK;
+    if (popc64(g) < 4) return ST_NONE;
+    double H[9];
+    if (!homography_ransac(g, p.X32[0], p.X32[1], p.u32, p.v32, 10.0, H)) return ST_NONE;
+    double fx, fy;
+    if (!k_from_homography(H, img_w / 2.0, img_h / 2.0, fx, fy)) return ST_NONE;   // build deviation, see oracle
+    c.fx = fx; c.fy = fy; c.cx = img_w / 2.0; c.cy = img_h / 2.0; c.ppx = c.cx; c.ppy = c.cy;
+    if (!cam_solve_pnp(c, mask, p)) return ST_RAISE;
+    cam_refine(c, mask, p);
+    c.rmse = cam_rmse(c, mask, p);
+    return ST_OK;
+}
+
+// prediction.py:523-555 + get_camera_gen :609-640 (exceptions inside are swallowed -> None)
+__device__ int camera_all_points(u64 mask, const Pts& p, int img_w, int img_h, Cam& c) {
+    View views[3];
+    const int nv = build_views(mask, 6, true, views);
+    double total = 0;
+    for (int i = 0; i < nv; ++i) total += views[i].weight * popc64(views[i].mask);
+    if (!(nv > 0 && total > 6)) return ST_NONE;
+    double f, R0[9], t0[3];
+    if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0)) return ST_NONE;
+    cam_from_calibration(c, f, R0, t0, img_w, img_h);
+    if (!cam_solve_pnp(c, mask, p)) return ST_NONE;            // always runs (quirk Q2)
+    if (popc64(mask) > 6) cam_refine(c, mask, p);
+    c.rmse = cam_rmse(c, mask, p);
+    return ST_OK;
+}
+
+// prediction.py:572-606
+__device__ int camera_accurate_points(u64 mask, const Pts& p, double thr, int img_w, int img_h, Cam& c) {
+    const int lane = threadIdx.x & 63;
+    const u64 g = mask & GROUND_MASK;
+    if (popc64(g) < 4) return ST_NONE;
+    double H[9];
+    if (!homography_ransac(g, p.X32[0], p.X32[1], p.u32, p.v32, thr, H)) return ST_NONE;
+    double pu, pv;
+    apply_h(H, p.X32[0], p.X32[1], pu, pv);
+    const double err = sqrt((pu - p.u32) * (pu - p.u32) + (pv - p.v32) * (pv - p.v32));
+    const u64 sel = __ballot(((g >> lane) & 1) && err < thr) | (mask & TOP_GATES_MASK);
+    return camera_all_points(sel, p, img_w, img_h, c);
+}
+
+__device__ u64 add_line_points(u64 mask, Pts& p, const float* line_pts, const sncal_voter_cfg& cfg, int mode,
+                               int n_ground_kp) {
+    // prediction.py:186-192 (mode 2), :270-278 (mode 1, voter), :356-364 (mode 0, original_voter)
+    if (!line_pts) return mask;
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < 30; ++i) {
+        const float lx = line_pts[i * 3 + 0], ly = line_pts[i * 3 + 1], valid = line_pts[i * 3 + 2];
+        if (!(valid > 0.5f) || ((mask >> i) & 1)) continue;
+        bool take;
+        if (mode == 0) take = n_ground_kp < cfg.min_points_per_plane || (0 <= lx && lx <= cfg.img_w && 0 <= ly && ly <= cfg.img_h);
+        else if (mode == 1) take = popc64(mask & GROUND_MASK) < cfg.min_points_per_plane;
+        else take = popc64(mask) <= cfg.min_points;
+        if (take) {
+            mask |= 1ull << i;
+            if (lane == i) { p.u = (double)lx; p.v = (double)ly; p.u32 = (double)lx; p.v32 = (double)ly; }
+        }
+    }
+    return mask;
+}
+
+__device__ u64 select_points(const float conf, double thr, bool reliable_rule, int reliable_thresh) {
+    const int lane = threadIdx.x & 63;
+    const bool det = lane < NPTS && (double)conf > thr;
+    const u64 dm = __ballot(det);
+    if (!reliable_rule || popc64(dm) < reliable_thresh) return dm;
+    return dm & KEEP_MASK;
+}
+
+// prediction.py:339-437
+__device__ int original_voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
+    u64 mask = select_points(kp[2], thr, true, cfg.reliable_thresh);
+    mask = add_line_points(mask, p, line_pts, cfg, 0, popc64(mask & GROUND_MASK));
+    Cam hom;
+    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+    if (hs == ST_RAISE) return ST_RAISE;
+    bool have = false;
+    View views[3];
+    const int nv = build_views(mask, cfg.min_points_per_plane, false, views);
+    if (nv > 0 && popc64(mask) > cfg.min_points) {
+        double f, R0[9], t0[3];
+        if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+        cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
+        out.tag = SNCAL_CAM_ORIGINAL;
+        have = true;
+        if (popc64(mask & GROUND_MASK) < cfg.min_points_per_plane && !cam_solve_pnp(out, mask, p)) return ST_RAISE;
+        if (!good_camera(out)) have = false;
+        else if (popc64(mask) > cfg.min_points_for_refinement) cam_refine(out, mask, p);
+    }
+    if (!have && hs == ST_OK && hom.rmse < 26) { out = hom; out.tag = SNCAL_CAM_ORIGINAL_HOM; have = true; }
+    if (!have) return ST_NONE;
+    out.rmse = cam_rmse(out, mask, p);
+    return ST_OK;
+}
+
+// prediction.py:259-330
+__device__ int voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
+    u64 mask = select_points(kp[2], thr, false, 0);
+    mask = add_line_points(mask, p, line_pts, cfg, 1, 0);
+    Cam hom;
+    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+    if (hs == ST_RAISE) return ST_RAISE;
+    Cam cands[4];
+    int st[4];
+    st[2] = camera_all_points(mask, p, cfg.img_w, cfg.img_h, cands[2]);
+    st[0] = camera_all_points(mask & KEEP_MASK, p, cfg.img_w, cfg.img_h, cands[0]);
+    st[1] = camera_accurate_points(mask, p, 5.0, cfg.img_w, cfg.img_h, cands[1]);
+    st[3] = camera_all_points(mask & GROUND_MASK, p, cfg.img_w, cfg.img_h, cands[3]);
+    const int tags[4] = {SNCAL_CAM_VOTER_REL, SNCAL_CAM_VOTER_ACC, SNCAL_CAM_VOTER_ALL, SNCAL_CAM_VOTER_GROUND};
+    int best = -1;
+    bool best_flag = false;
+    double best_inv = 0;
+    for (int i = 0; i < 4; ++i) {          // python max(): first maximum of (flag, 1/rmse) in list order
+        if (st[i] != ST_OK || !good_camera(cands[i])) continue;
+        if (cands[i].rmse == 0.0) return ST_RAISE;                    // 1/0 -> ZeroDivisionError (quirk Q5)
+        const bool flag = i == 0 && cands[i].rmse < cfg.max_rmse_rel;
+        const double inv = 1.0 / cands[i].rmse;
+        if (best < 0 || (flag && !best_flag) || (flag == best_flag && inv > best_inv)) { best = i; best_flag = flag; best_inv = inv; }
+    }
+    if (best >= 0 && cands[best].rmse < cfg.max_rmse) { out = cands[best]; out.tag = tags[best]; return ST_OK; }
+    if (hs == ST_OK && hom.rmse < cfg.max_rmse) { out = hom; out.tag = SNCAL_CAM_VOTER_HOM; return ST_OK; }
+    return ST_NONE;
+}
+
+// prediction.py:138-170
+__device__ int opencv_calibration(const float* kp, const sncal_voter_cfg& cfg, const Pts& p, Cam& out) {
+    const int lane = threadIdx.x & 63;
+    const u64 mask = __ballot(lane < NPTS && (double)kp[2] > cfg.conf_thresh) & GROUND_MASK;
+    if (popc64(mask) <= 5) return ST_NONE;
+    View v{mask, 0, 1.0};
+    double f, R0[9], t0[3];
+    if (!calibrate_planes(&v, 1, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+    cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
+    out.tag = SNCAL_CAM_ORIGINAL;
+    out.rmse = cam_rmse(out, mask, p);
+    return ST_OK;
+}
+
+// prediction.py:172-243
+__device__ int opencv_calibration_multiplane(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, Pts p, Cam& out) {
+    u64 mask = select_points(kp[2], cfg.conf_thresh, true, cfg.reliable_thresh);
+    mask = add_line_points(mask, p, line_pts, cfg, 2, 0);
+    View views[3];
+    const int nv = build_views(mask, cfg.min_points_per_plane, false, views);
+    if (!(nv > 0 && popc64(mask) > cfg.min_points)) return ST_NONE;
+    double f, R0[9], t0[3];
+    if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+    if (!(f > cfg.min_focal_length)) return ST_NONE;
+    cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
+    if (popc64(mask) > cfg.min_points_for_refinement) cam_refine(out, mask, p);
+    out.tag = SNCAL_CAM_ORIGINAL;
+    out.rmse = cam_rmse(out, mask, p);
+    return ST_OK;
+}
+
+__device__ void load_points(const float* kp, Pts& p) {
+    const int lane = threadIdx.x & 63;
+    const int id = lane < NPTS ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { p.X64[i] = c_P64[id * 3 + i]; p.X32[i] = c_P32[id * 3 + i]; }
+    p.u = (double)kp[0]; p.v = (double)kp[1];      // float(pred[i,0]) -> python float; float32 -> float64 is exact
+    p.u32 = p.u; p.v32 = p.v;
+}
+
+__global__ __launch_bounds__(64) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
+                                                       int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out) {
+    const int frame = blockIdx.x;
+    if (frame >= B) return;
+    const int lane = threadIdx.x & 63;
+    float kp[3] = {0.f, 0.f, -1.f};
+    if (lane < NPTS) {
+        const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
+        kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
+    }
+    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    Pts p;
+    load_points(kp, p);
+    Cam cam;
+    cam.tag = SNCAL_CAM_NONE;
+    int st = ST_NONE;
+    switch (cfg.algorithm) {
+        case 0: {   // iterative_voter, prediction.py:245-257
+            st = original_voter(kp, lp, cfg, 0.5, p, cam);
+            if (st != ST_OK) {
+                st = ST_NONE;
+                for (int i = 0; i < cfg.n_conf_threshs; ++i) {
+                    st = voter(kp, lp, cfg, cfg.conf_threshs[i], p, cam);
+                    if (st != ST_NONE) break;   // camera found, or an exception leaves iterative_voter
+                }
+            }
+            break;
+        }
+        case 1: st = original_voter(kp, lp, cfg, cfg.conf_thresh, p, cam); break;
+        case 2: st = voter(kp, lp, cfg, cfg.conf_thresh, p, cam); break;
+        case 3: st = opencv_calibration(kp, cfg, p, cam); break;
+        default: st = opencv_calibration_multiplane(kp, lp, cfg, p, cam); break;
+    }
+    if (lane == 0) {
+        sncal_camera o;
+        memset(&o, 0, sizeof(o));
+        if (st == ST_OK) {
+            for (int i = 0; i < 3; ++i) o.position[i] = cam.pos[i];
+            for (int i = 0; i < 9; ++i) o.rotation[i] = cam.R[i];
+            o.fx = cam.fx; o.fy = cam.fy; o.cx = cam.cx; o.cy = cam.cy; o.rmse = cam.rmse;
+            o.status = cam.tag;
+        }
+        out[frame] = o;
+    }
+}
+
+// stand-alone Camera.refine_camera / Camera.solve_pnp on caller-provided 3-D / 2-D matches
+__global__ __launch_bounds__(64) void pnp_kernel(const double* __restrict__ Kin, const double* __restrict__ p3,
+                                                 const double* __restrict__ p2, const int* __restrict__ npts, int N,
+                                                 double* __restrict__ rt, double* __restrict__ rmse, int mode,
+                                                 int max_iters, double eps) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int n = min(npts[b], min(N, 64));
+    const bool in = lane < n;
+    double X[3] = {0, 0, 0}, u = 0, v = 0;
+    if (in) {
+        const double* q = p3 + ((size_t)b * N + lane) * 3;
+        X[0] = q[0]; X[1] = q[1]; X[2] = q[2];
+        u = p2[((size_t)b * N + lane) * 2]; v = p2[((size_t)b * N + lane) * 2 + 1];
+    }
+    const u64 mask = n >= 64 ? ~0ull : ((1ull << n) - 1);
+    const K4 k{Kin[b * 4 + 0], Kin[b * 4 + 1], Kin[b * 4 + 2], Kin[b * 4 + 3]};
+    double R[9], t[3], pos[3];
+    for (int i = 0; i < 9; ++i) R[i] = rt[b * 12 + i];
+    for (int i = 0; i < 3; ++i) pos[i] = rt[b * 12 + 9 + i];
+    bool ok = true;
+    if (mode == 0) {
+        for (int i = 0; i < 3; ++i) t[i] = -(R[i * 3] * pos[0] + R[i * 3 + 1] * pos[1] + R[i * 3 + 2] * pos[2]);
+        refine_pose_lm(mask, R, t, k, X, u, v, max_iters, eps);
+    } else {
+        // ground plane membership for the minimal solver = points with z == 0
+        const u64 gm = __ballot(in && X[2] == 0.0);
+        // pnp_ransac samples from (mask & GROUND_MASK); remap: run it on a mask whose ground subset is gm
+        const int ng = popc64(gm);
+        ok = ng >= 4;
+        if (ok) {
+            int idx[4] = {0, 0, 0, 0};
+            bool hok = sample4(lane, ng, idx);
+            double s[4][2], d[4][2];
+            for (int q = 0; q < 4; ++q) {
+                const int src = kth_set_bit(gm, idx[q]);
+                s[q][0] = __shfl(X[0], src, 64); s[q][1] = __shfl(X[1], src, 64);
+                d[q][0] = __shfl(u, src, 64); d[q][1] = __shfl(v, src, 64);
+            }
+            double Hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Rh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, th[3] = {0, 0, 1};
+            hok = hok && homography_4pt(s, d, Hh) && pose_from_homography(Hh, k.fx, k.fy, k.cx, k.cy, Rh, th);
+            int cnt = 0;
+            double se = 0;
+            for (u64 m = mask; m; m &= m - 1) {
+                const int j = __ffsll((long long)m) - 1;
+                const double Xj[3] = {bcast(X[0], j), bcast(X[1], j), bcast(X[2], j)};
+                const double uj = bcast(u, j), vj = bcast(v, j);
+                if (hok) {
+                    double z;
+                    const double e2 = reproj_e2(Rh, th, k, Xj, uj, vj, &z);
+                    if (e2 <= 64.0 && z > 1e-9) { ++cnt; se += e2; }
+                }
+            }
+            const Best best = wave_best(Best{hok ? cnt : -1, hok ? se : INFINITY, lane});
+            ok = best.cnt >= 4;
+            if (ok) {
+                for (int i = 0; i < 9; ++i) R[i] = bcast(Rh[i], best.h);
+                for (int i = 0; i < 3; ++i) t[i] = bcast(th[i], best.h);
+                double z;
+                const double e2 = reproj_e2(R, t, k, X, u, v, &z);
+                const u64 inl = __ballot(in && e2 <= 64.0 && z > 1e-9);
+                refine_pose_lm(inl, R, t, k, X, u, v, 20, 1e-10);
+            }
+        }
+    }
+    if (lane == 0 && ok) {
+        for (int i = 0; i < 9; ++i) rt[b * 12 + i] = R[i];
+        rt[b * 12 + 9] = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]);
+        rt[b * 12 + 10] = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]);
+        rt[b * 12 + 11] = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+    }
+    if (rmse) {
+        double z;
+        const double e2 = reproj_e2(R, t, k, X, u, v, &z);
+        const double m = wsum(in ? sqrt(e2) : 0.0) / (double)(n > 0 ? n : 1);
+        if (lane == 0) rmse[b] = ok ? m : -1.0;
+    }
+}
+
+// ---- host: pitch template upload ----------------------------------------------------------------------
+void tangent_points(const double* c, double r, const double* p, double* a, double* b) {   // ellipse.py:20-33
+    const double hyp = std::sqrt((p[0] - c[0]) * (p[0] - c[0]) + (p[1] - c[1]) * (p[1] - c[1]));
+    const double th = std::acos(r / hyp), d = std::atan2(p[1] - c[1], p[0] - c[0]);
+    a[0] = c[0] + r * std::cos(d + th); a[1] = c[1] + r * std::sin(d + th); a[2] = 0;
+    b[0] = c[0] + r * std::cos(d - th); b[1] = c[1] + r * std::sin(d - th); b[2] = 0;
+}
+
+void build_pitch(double (*P)[3]) {   // soccerpitch.py:109-263 + ellipse.py:16-92, ids per ellipse.py:99-157
+    const double hl = 52.5, hw = 34.0, PL = 16.5, PW = 40.32, GL = 5.5, GW = 18.32, PM = 11.0, Rr = 9.15, gy = 3.66, GH = 2.44;
+    auto set = [&](int i, double x, double y, double z) { P[i][0] = x; P[i][1] = y; P[i][2] = z; };
+    set(0, -hl, gy, -GH); set(1, -hl, -gy, -GH); set(2, -hl, gy, 0); set(3, -hl, -gy, 0);
+    set(4, -hl + GL, GW / 2, 0); set(5, -hl + GL, -GW / 2, 0); set(6, -hl, GW / 2, 0); set(7, -hl, -GW / 2, 0);
+    set(8, -hl + PL, PW / 2, 0); set(9, -hl + PL, -PW / 2, 0); set(10, -hl, PW / 2, 0); set(11, -hl, -PW / 2, 0);
+    set(12, -hl, hw, 0); set(13, -hl, -hw, 0); set(14, 0, hw, 0); set(15, 0, -hw, 0);
+    set(16, hl - PL, PW / 2, 0); set(17, hl - PL, -PW / 2, 0); set(18, hl, PW / 2, 0); set(19, hl, -PW / 2, 0);
+    set(20, hl - GL, GW / 2, 0); set(21, hl - GL, -GW / 2, 0); set(22, hl, GW / 2, 0); set(23, hl, -GW / 2, 0);
+    set(24, hl, -gy, -GH); set(25, hl, gy, -GH); set(26, hl, -gy, 0); set(27, hl, gy, 0);
+    set(28, hl, hw, 0); set(29, hl, -hw, 0);
+    const double c0[2] = {0, 0};
+    double a[3], b[3];
+    tangent_points(c0, Rr, P[15], a, b);
+    set(30, a[0], a[1], 0); set(31, b[0], b[1], 0);
+    tangent_points(c0, Rr, P[14], a, b);
+    set(32, b[0], b[1], 0); set(33, a[0], a[1], 0);
+    const double s = std::sqrt(2.0) * Rr / 2;
+    set(34, s, -s, 0); set(35, -s, -s, 0); set(36, s, s, 0); set(37, -s, s, 0);
+    set(38, Rr, 0, 0); set(39, -Rr, 0, 0); set(40, 0, -Rr, 0); set(41, 0, Rr, 0); set(42, 0, 0, 0);
+    const double lpm[2] = {-hl + PM, 0}, rpm[2] = {hl - PM, 0};
+    const double dx = PL - PM, ay = std::sqrt(Rr * Rr - dx * dx);
+    set(43, lpm[0] + Rr, 0, 0); set(44, -hl + PL, ay, 0); set(45, -hl + PL, -ay, 0);
+    tangent_points(lpm, Rr, P[9], a, b); set(46, a[0], a[1], 0);
+    tangent_points(lpm, Rr, P[8], a, b); set(47, b[0], b[1], 0);
+    set(48, lpm[0], 0, 0); set(49, P[8][0], 0, 0);
+    set(50, rpm[0] - Rr, 0, 0); set(51, hl - PL, ay, 0); set(52, hl - PL, -ay, 0);
+    tangent_points(rpm, Rr, P[17], a, b); set(53, b[0], b[1], 0);
+    tangent_points(rpm, Rr, P[16], a, b); set(54, a[0], a[1], 0);
+    set(55, rpm[0], 0, 0); set(56, P[16][0], 0, 0);
+}
+
+int ensure_pitch_uploaded() {
+    static std::once_flag once;
+    static int rc = SNCAL_OK;
+    // constant memory is per device: upload for the current device every time it changes
+    static thread_local int last_dev = -1;
+    int dev = 0;
+    SNCAL_CHECK_HIP(hipGetDevice(&dev));
+    if (dev == last_dev) return rc;
+    double P[NPTS][3], P32[NPTS][3];
+    build_pitch(P);
+    for (int i = 0; i < NPTS; ++i)
+        for (int j = 0; j < 3; ++j) P32[i][j] = (double)(float)P[i][j];
+    SNCAL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_P64), P, sizeof(P)));
+    SNCAL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_P32), P32, sizeof(P32)));
+    last_dev = dev;
+    (void)once;
+    return SNCAL_OK;
+}
+
+}  // namespace
+
+extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                               sncal_camera* d_out, void* stream) {
+    SNCAL_CHECK_ARG(B >= 0 && cfg, "sncal_calibrate: bad arguments");
+    if (B == 0) return SNCAL_OK;
+    SNCAL_CHECK_ARG(d_kpts && d_out, "sncal_calibrate: null pointer");
+    SNCAL_CHECK_ARG(cfg->algorithm >= 0 && cfg->algorithm <= 4, "sncal_calibrate: algorithm %d", cfg->algorithm);
+    SNCAL_CHECK_ARG(cfg->n_conf_threshs >= 0 && cfg->n_conf_threshs <= 4, "sncal_calibrate: n_conf_threshs");
+    SNCAL_CHECK_ARG(cfg->img_w > 1 && cfg->img_h > 1, "sncal_calibrate: image size");
+    const int rc = ensure_pitch_uploaded();
+    if (rc) return rc;
+    hipLaunchKernelGGL(calibrate_kernel, dim3(B), dim3(64), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+static int launch_pnp(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts, int B, int N,
+                      double* d_rt, double* d_rmse, int mode, int max_iters, double eps, void* stream) {
+    SNCAL_CHECK_ARG(B >= 0 && N > 0 && N <= 64, "pnp: need 0 < N <= 64 points per frame (got %d)", N);
+    if (B == 0) return SNCAL_OK;
+    SNCAL_CHECK_ARG(d_K && d_pts3d && d_pts2d && d_npts && d_rt, "pnp: null pointer");
+    hipLaunchKernelGGL(pnp_kernel, dim3(B), dim3(64), 0, sncal::as_stream(stream), d_K, d_pts3d, d_pts2d, d_npts, N, d_rt,
+                       d_rmse, mode, max_iters, eps);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,
+                                   int B, int N, double* d_rt, double* d_rmse, int max_iters, double eps, void* stream) {
+    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : 100,
+                      eps > 0 ? eps : 1e-10, stream);
+}
+
+extern "C" int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,
+                               int B, int N, double* d_rt, void* stream) {
+    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, nullptr, 1, 20, 1e-10, stream);
+}

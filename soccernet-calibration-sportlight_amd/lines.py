@@ -1,0 +1,97 @@
+"""Line-model post-processing and the line -> keypoint join (host logic, python floats like the reference).
+
+LINE_CLS            <-> /root/reference/src/datatools/line.py:35-57
+LINE_INTERSECTIONS  <-> /root/reference/src/datatools/intersections.py:13-44
+calculate_slope_intercept / get_line_data <-> /root/reference/src/utils/export_line_result.py:51-131
+line_eq_intersection / lines_to_keypoints <-> /root/reference/src/models/hrnet/prediction.py:105-124, 643-653
+The pickle schema {img: {'lines': [ {name: (k, b)} ], 'points': [ {name: [(x,y,p)]} ]}} is the reference's
+(export_line_result.py:188, 200-201; consumed at prediction.py:107-124).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+LINE_CLS: Dict[int, str] = dict(enumerate([
+    'Goal left post left ', 'Goal right post right', 'Middle line', 'Small rect. right top', 'Side line bottom',
+    'Goal right post left', 'Big rect. right main', 'Goal left crossbar', 'Small rect. left bottom',
+    'Side line left', 'Big rect. right top', 'Small rect. left top', 'Side line right', 'Big rect. left top',
+    'Goal left post right', 'Small rect. right bottom', 'Side line top', 'Goal right crossbar',
+    'Small rect. left main', 'Big rect. left main', 'Big rect. right bottom', 'Small rect. right main',
+    'Big rect. left bottom']))
+
+LINE_INTERSECTIONS: Dict[int, Tuple[str, str]] = {}
+LINE_INTERSECTIONS.update({
+    0: ('Goal left crossbar', 'Goal left post left '), 1: ('Goal left crossbar', 'Goal left post right'),
+    2: ('Side line left', 'Goal left post left '), 3: ('Side line left', 'Goal left post right'),
+    4: ('Small rect. left main', 'Small rect. left bottom'), 5: ('Small rect. left main', 'Small rect. left top'),
+    6: ('Side line left', 'Small rect. left bottom'), 7: ('Side line left', 'Small rect. left top'),
+    8: ('Big rect. left main', 'Big rect. left bottom'), 9: ('Big rect. left main', 'Big rect. left top'),
+    10: ('Side line left', 'Big rect. left bottom'), 11: ('Side line left', 'Big rect. left top'),
+    12: ('Side line left', 'Side line bottom'), 13: ('Side line left', 'Side line top'),
+    14: ('Middle line', 'Side line bottom'), 15: ('Middle line', 'Side line top'),
+    16: ('Big rect. right main', 'Big rect. right bottom'), 17: ('Big rect. right main', 'Big rect. right top'),
+    18: ('Side line right', 'Big rect. right bottom'), 19: ('Side line right', 'Big rect. right top'),
+    20: ('Small rect. right main', 'Small rect. right bottom'), 21: ('Small rect. right main', 'Small rect. right top'),
+    22: ('Side line right', 'Small rect. right bottom'), 23: ('Side line right', 'Small rect. right top'),
+    24: ('Goal right crossbar', 'Goal right post left'), 25: ('Goal right crossbar', 'Goal right post right'),
+    26: ('Side line right', 'Goal right post left'), 27: ('Side line right', 'Goal right post right'),
+    28: ('Side line right', 'Side line bottom'), 29: ('Side line right', 'Side line top'),
+})
+
+
+def calculate_slope_intercept(point1, point2, delta: float = 0.00001):
+    if tuple(point1) == tuple(point2):
+        return None, None
+    x1, y1 = point1
+    x2, y2 = point2
+    slope = (y2 - y1) / (x2 - x1 + delta)
+    return slope, y1 - slope * x1
+
+
+def get_line_data(heat_loc, scale=4, prob_thre: float = 0.2):
+    """heat_loc (1,K,2,3) rows [x, y, p] (numpy or torch) -> ({name: (k, b)}, {name: [(x,y,p)]})."""
+    if hasattr(heat_loc, 'cpu'):
+        heat_loc = heat_loc.cpu().numpy()
+    _, ks, num_heats, _ = heat_loc.shape
+    line_paras, final_points = {}, {}
+    for k in range(ks):
+        valid_points = []
+        for n in range(num_heats):
+            x, y, p = heat_loc[0, k, n]
+            if p >= prob_thre:
+                valid_points.append((x * scale, y * scale, p))
+        final_points[LINE_CLS[k]] = valid_points
+        if len(valid_points) >= 2:
+            line_paras[LINE_CLS[k]] = calculate_slope_intercept(valid_points[0][:2], valid_points[1][:2])
+    return line_paras, final_points
+
+
+def line_eq_intersection(line1, line2) -> Optional[Tuple[float, float]]:
+    k1, b1 = line1
+    k2, b2 = line2
+    if abs(k1 - k2) > 1e-4:
+        x = (b2 - b1) / (k1 - k2)
+        return (x, k1 * x + b1)
+    return None
+
+
+def lines_to_keypoints(pred: Dict[str, Tuple[float, float]]) -> Dict[int, Tuple[float, float]]:
+    """One image's {line name: (slope, intercept)} -> {keypoint id 0..29: (x, y)} (prediction.py:110-124)."""
+    pred = dict(pred)
+    if 'Goal left post left' in pred:
+        pred['Goal left post left '] = pred.pop('Goal left post left')
+    points = {}
+    for idx, pair in LINE_INTERSECTIONS.items():
+        if pair[0] in pred and pair[1] in pred:
+            ip = line_eq_intersection(pred[pair[0]], pred[pair[1]])
+            if ip is not None:
+                points[idx] = ip
+    return points
+
+
+def keypoints_to_array(points: Dict[int, Tuple[float, float]]) -> np.ndarray:
+    """{id: (x,y)} -> (30,3) float32 rows [x, y, valid] for sncal_calibrate's d_line_pts."""
+    a = np.zeros((30, 3), dtype=np.float32)
+    for i, (x, y) in points.items():
+        a[i] = (x, y, 1.0)
+    return a

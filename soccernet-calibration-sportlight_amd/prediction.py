@@ -1,0 +1,172 @@
+"""CameraCreator -- host mirror of /root/reference/src/models/hrnet/prediction.py:44-437.
+
+Same constructor (pitch, img_size, conf_thresh, algorithm, lines_file, **kwargs -> attributes), same
+``__call__(pred (57,3) float32, name) -> Optional[Camera]`` that never raises, same five algorithm names,
+picklable (it holds only python data, so it can be shipped to worker processes exactly like the reference's
+at make_submit.py:53-54,69).  The solve itself -- every heuristic of the reference's voters -- runs on the
+GPU: one wavefront per frame in sncal_calibrate (csrc/solve.hip).  ``solve_batch`` is the batched entry the
+frame pipeline uses; ``__call__`` is the one-frame form of it.
+"""
+import ctypes
+import os
+import pickle
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .camera import Camera
+from .lines import lines_to_keypoints, keypoints_to_array, line_eq_intersection  # noqa: F401
+from .pitch import PITCH_POINTS, INTERSECTON_TO_PITCH_POINTS, IMG_SIZE, top_gates, point_sets, keep_points  # noqa: F401
+
+ALGORITHMS = {'iterative_voter': 0, 'original_voter': 1, 'voter': 2, 'opencv_calibration': 3,
+              'opencv_calibration_multiplane': 4}
+STATUS_NAMES = {0: None, 1: 'original_voter', 2: 'original_voter_hom', 3: 'camera_rel', 4: 'camera_acc',
+                5: 'cam_all', 6: 'cam_ground', 7: 'voter_hom'}
+
+
+def swap_z_y(point_3d):
+    point_3d = point_3d.copy()
+    point_3d[0] = point_3d[1]
+    point_3d[1] = point_3d[2]
+    point_3d[2] = 0.0
+    return point_3d
+
+
+def good_camera(mtx, pos):
+    return bool(10 <= mtx[0, 0] <= 20000 and -250 < pos[0] < 250 and -250 < pos[1] < 250 and -100 < pos[2] < 0)
+
+
+def is_good_camera(cam: Camera):
+    return good_camera(cam.calibration, cam.position)
+
+
+def camera_from_record(rec, img_size=IMG_SIZE) -> Optional[Camera]:
+    """sncal_camera (ctypes) -> Camera with the attribute values the reference leaves behind."""
+    if rec.status == 0:
+        return None
+    cam = Camera(*img_size)
+    cam.position = np.array(rec.position[:], dtype=np.float64)
+    cam.rotation = np.array(rec.rotation[:], dtype=np.float64).reshape(3, 3)
+    cam.calibration = np.array([[rec.fx, 0.0, rec.cx], [0.0, rec.fy, rec.cy], [0.0, 0.0, 1.0]])
+    cam.xfocal_length = np.float64(rec.fx)
+    cam.yfocal_length = np.float64(rec.fy)
+    cam.principal_point = (img_size[0] / 2.0, img_size[1] / 2.0)
+    cam.rmse = float(rec.rmse)
+    cam.source = STATUS_NAMES.get(rec.status, str(rec.status))
+    return cam
+
+
+class CameraCreator:
+    def __init__(self, pitch: Dict[str, np.ndarray] = None, img_size: Tuple[int, int] = (960, 540),
+                 conf_thresh: float = 0.2, algorithm: str = 'opencv_calibration', lines_file=None, **kwargs):
+        assert algorithm in ALGORITHMS, f'Should be one of: {list(ALGORITHMS.keys())}'
+        self.algorithm_name = algorithm
+        self.conf_thresh = conf_thresh
+        self.pitch = pitch if pitch is not None else PITCH_POINTS
+        for i, name in INTERSECTON_TO_PITCH_POINTS.items():      # the device template is fixed: refuse another pitch
+            if name in self.pitch and not np.allclose(self.pitch[name], PITCH_POINTS[name], atol=1e-9):
+                raise ValueError(f'pitch point {name} differs from the built-in 105x68 m template')
+        self.img_size = tuple(img_size)
+        self.lines_data = {}
+        if lines_file is not None:
+            assert os.path.exists(lines_file), f'{lines_file} does not exist'
+            with open(lines_file, 'rb') as f:
+                lines_data = pickle.load(f)
+            for img_name in lines_data.keys():
+                points = lines_to_keypoints(lines_data[img_name]['lines'][0])
+                if len(points) > 0:
+                    self.lines_data[img_name] = points
+        # defaults of the kwargs make_submit.py:45-50 passes
+        self.conf_threshs = [0.5, 0.35, 0.2]
+        self.max_rmse, self.max_rmse_rel = 55.0, 5.0
+        self.min_points, self.min_focal_length = 5, 10.0
+        self.min_points_per_plane, self.min_points_for_refinement, self.reliable_thresh = 6, 6, 57
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+        self.stat = {'n': 0, 'frames_4': 0, 'frames_4_6': 0, 'frames_bad_cam': 0}
+
+    # ---- C ABI plumbing -------------------------------------------------------------------------------
+    def _cfg(self):
+        c = _lib.VoterCfg()
+        c.algorithm = ALGORITHMS[self.algorithm_name]
+        c.conf_thresh = float(self.conf_thresh)
+        ths = list(self.conf_threshs)[:4]
+        c.n_conf_threshs = len(ths)
+        for i, t in enumerate(ths):
+            c.conf_threshs[i] = float(t)
+        c.max_rmse, c.max_rmse_rel = float(self.max_rmse), float(self.max_rmse_rel)
+        c.min_points, c.min_points_per_plane = int(self.min_points), int(self.min_points_per_plane)
+        c.min_points_for_refinement, c.reliable_thresh = int(self.min_points_for_refinement), int(self.reliable_thresh)
+        c.min_focal_length = float(self.min_focal_length)
+        c.img_w, c.img_h = int(self.img_size[0]), int(self.img_size[1])
+        return c
+
+    def line_points_array(self, names):
+        """(B,30,3) float32 [x, y, valid] from the ingested lines file, or None if no frame has any."""
+        if not self.lines_data or names is None:
+            return None
+        arr = np.zeros((len(names), 30, 3), dtype=np.float32)
+        hit = False
+        for b, n in enumerate(names):
+            if n is not None and n in self.lines_data:
+                arr[b] = keypoints_to_array(self.lines_data[n])
+                hit = True
+        return arr if hit else None
+
+    def solve_device(self, d_kpts, d_line_pts=None, out=None):
+        """Batched solve on device tensors: d_kpts (B,57,3) float32 cuda -> uint8 cuda tensor of B sncal_camera
+        records (asynchronous on the current stream)."""
+        import torch
+        _lib.require_device(d_kpts, torch.float32, 'kpts')
+        B = d_kpts.shape[0]
+        if tuple(d_kpts.shape[1:]) != (57, 3):
+            raise _lib.SncalError('kpts must be (B,57,3)')
+        if d_line_pts is not None:
+            _lib.require_device(d_line_pts, torch.float32, 'line_pts')
+        if out is None:
+            out = torch.empty((B, ctypes.sizeof(_lib.Camera)), dtype=torch.uint8, device=d_kpts.device)
+        cfg = self._cfg()
+        with torch.cuda.device(d_kpts.device):
+            _lib.check(_lib.lib().sncal_calibrate(d_kpts.data_ptr(), d_line_pts.data_ptr() if d_line_pts is not None else None,
+                                                  B, ctypes.byref(cfg), out.data_ptr(), _lib.current_stream_ptr()),
+                       'sncal_calibrate')
+        return out
+
+    @staticmethod
+    def records(out_tensor):
+        """uint8 device tensor from solve_device -> ctypes array of sncal_camera (synchronises)."""
+        host = out_tensor.cpu().numpy().tobytes()
+        n = len(host) // ctypes.sizeof(_lib.Camera)
+        return (_lib.Camera * n).from_buffer_copy(host)
+
+    def solve_batch(self, preds, names=None):
+        """preds (B,57,3) float32 (numpy or torch, any device) -> list of Optional[Camera]."""
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.SncalError('CameraCreator needs a GPU (libsncal.so has no CPU path)')
+        t = preds if isinstance(preds, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(preds, dtype=np.float32))
+        if not t.is_cuda:
+            t = t.to('cuda')
+        t = t.contiguous().float()
+        lp = self.line_points_array(names)
+        d_lp = torch.from_numpy(lp).to(t.device) if lp is not None else None
+        recs = self.records(self.solve_device(t, d_lp))
+        return [camera_from_record(r, self.img_size) for r in recs]
+
+    def __call__(self, pred, name: Optional[str] = None) -> Optional[Camera]:
+        cam = None
+        try:
+            cam = self.solve_batch(np.asarray(pred, dtype=np.float32)[None], [name])[0]
+        except Exception as e:      # the reference's firewall (prediction.py:130-136)
+            print(f'Camera initialization exc: {e}')
+        return cam
+
+    def _get_points_from_lines(self, name=None):
+        if self.lines_data is not None and name is not None and name in self.lines_data:
+            return self.lines_data[name]
+        return {}
+
+
+def get_matched_points(camera_points):
+    return [(PITCH_POINTS[INTERSECTON_TO_PITCH_POINTS[i]], camera_points[i]) for i in camera_points]

@@ -172,7 +172,7 @@ def gen_camera():
         cam = synth.sample_camera(rng)
         c = Camera(960, 540)
         c.position = cam['position'].copy(); c.rotation = cam['rotation'].copy()
-        c.xfocal_length = c.yfocal_length = cam['f']
+        c.xfocal_length = c.yfocal_length = np.float64(cam['f'])   # cv2 / numpy matrices hold float64
         c.calibration = np.array([[cam['f'], 0, 480.], [0, cam['f'], 270.], [0, 0, 1.]])
         proj = np.stack([c.project_point(p) for p in P])
         mine = np.stack([cm.project_point(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.), p) for p in P])

@@ -292,6 +292,40 @@ def refine_pose_lm(R, t, K4, X, uv, max_iters: int = 100, eps: float = 1e-10):
     return _polar(R), t
 
 
+def polish4(R, t, K4, X4, uv4):
+    """Damped Gauss-Newton polish of a minimal-sample pose on its own 4 points (shared spec with solve.hip):
+    the closed-form homography decomposition is badly conditioned for long focal lengths."""
+    def cost(R_, t_):
+        p, _ = project(R_, t_, K4, X4)
+        return float(((p - uv4) ** 2).sum())
+    c0 = cost(R, t)
+    for _ in range(8):
+        Xc = X4 @ R.T + t
+        z = np.where(np.abs(Xc[:, 2]) < 1e-12, 1e-12, Xc[:, 2])
+        x, y = Xc[:, 0] / z, Xc[:, 1] / z
+        r = np.zeros(8)
+        r[0::2], r[1::2] = K4[0] * x + K4[2] - uv4[:, 0], K4[1] * y + K4[3] - uv4[:, 1]
+        J = np.zeros((8, 6))
+        du = np.c_[K4[0] / z, np.zeros_like(z), -K4[0] * x / z]
+        dv = np.c_[np.zeros_like(z), K4[1] / z, -K4[1] * y / z]
+        for row, d in ((0, du), (1, dv)):
+            J[row::2, 0] = d[:, 2] * Xc[:, 1] - d[:, 1] * Xc[:, 2]
+            J[row::2, 1] = d[:, 0] * Xc[:, 2] - d[:, 2] * Xc[:, 0]
+            J[row::2, 2] = d[:, 1] * Xc[:, 0] - d[:, 0] * Xc[:, 1]
+            J[row::2, 3:6] = d
+        A = J.T @ J
+        step = chol_solve(A + 1e-3 * np.diag(np.diag(A)), -(J.T @ r))
+        if step is None:
+            break
+        E = exp_so3(step[:3])
+        Rn, tn = E @ R, E @ t + step[3:]
+        c1 = cost(Rn, tn)
+        if not c1 < c0:
+            break
+        R, t, c0 = Rn, tn, c1
+    return R, t
+
+
 def pnp_ransac(K4, X, uv, ground_mask):
     """camera.py:92-103 solve_pnp = cv.solvePnPRansac(obj, img, K, None) + Rodrigues.
     Minimal solver: planar pose from 4 ground points; inliers at 8 px; LM refit on the inliers.
@@ -311,6 +345,19 @@ def pnp_ransac(K4, X, uv, ground_mask):
             pose = pose_from_homography(H, *K4)
             if pose is None:
                 continue
+            X4 = np.c_[X[sel, :2], np.zeros(4)]
+            pose = polish4(pose[0], pose[1], K4, X4, uv[sel])
+            p, z = project(pose[0], pose[1], K4, X)
+            e2 = ((p - uv) ** 2).sum(1)
+            inl = (e2 <= 64.0) & (z > 1e-9)
+            cnt, s = int(inl.sum()), float(e2[inl].sum())
+            if cnt > best[0] or (cnt == best[0] and s < best[1]):
+                best = (cnt, s, (pose, inl))
+    if n >= 4:      # hypothesis NH_PNP: least-squares homography over every z=0 point
+        H = homography_lsq(X[gi, :2], uv[gi], iters=10)
+        pose = pose_from_homography(H, *K4) if H is not None else None
+        if pose is not None:
+            pose = refine_pose_lm(pose[0], pose[1], K4, X[gi], uv[gi], max_iters=20)
             p, z = project(pose[0], pose[1], K4, X)
             e2 = ((p - uv) ** 2).sum(1)
             inl = (e2 <= 64.0) & (z > 1e-9)

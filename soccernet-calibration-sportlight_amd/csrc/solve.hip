@@ -503,10 +503,54 @@ __device__ void refine_pose_lm(u64 mask, double* R, double* t, const K4& k, cons
     polar3(R);
 }
 
-// Camera.solve_pnp (camera.py:92-103): planar minimal solver on ground points + 8 px inliers + LM refit
-__device__ bool pnp_ransac(u64 mask, const K4& k, const double* X, double u, double v, double* R, double* t) {
+// Lane-local damped Gauss-Newton polish of a minimal-sample pose on its own 4 (z=0) points.  The closed-form
+// homography decomposition is badly conditioned for long focal lengths; a few iterations repair it.
+__device__ void polish4(double* R, double* t, const K4& k, const double (&s)[4][2], const double (&d)[4][2]) {
+    auto cost = [&](const double* R_, const double* t_) {
+        double c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double Xq[3] = {s[q][0], s[q][1], 0.0};
+            double z;
+            c += reproj_e2(R_, t_, k, Xq, d[q][0], d[q][1], &z);
+        }
+        return c;
+    };
+    double c0 = cost(R, t);
+    for (int it = 0; it < 8; ++it) {
+        double A[6][6], g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { g[i] = 0; for (int j = 0; j < 6; ++j) A[i][j] = 0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double Xq[3] = {s[q][0], s[q][1], 0.0};
+            double ju[6], jv[6], ru, rv, xn, yn;
+            pose_rows(R, t, k.fx, k.fy, k.cx, k.cy, Xq, d[q][0], d[q][1], ju, jv, ru, rv, xn, yn);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) A[i][j] += ju[i] * ju[j] + jv[i] * jv[j];
+                g[i] -= ju[i] * ru + jv[i] * rv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i][i] += 1e-3 * A[i][i];
+        double step[6] = {0, 0, 0, 0, 0, 0}, Rn[9], tn[3];
+        if (!chol_solve<6>(A, g, step)) break;
+        apply_step(R, t, step, Rn, tn);
+        const double c1 = cost(Rn, tn);
+        if (!(c1 < c0)) break;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        t[0] = tn[0]; t[1] = tn[1]; t[2] = tn[2];
+        c0 = c1;
+    }
+}
+
+// Camera.solve_pnp (camera.py:92-103): planar minimal solver on the z=0 points (64 lane-parallel 4-point
+// hypotheses + one least-squares homography over all of them), 8 px inliers, LM refit on the inliers
+__device__ bool pnp_ransac(u64 mask, u64 gmask, const K4& k, const double* X, double u, double v, double* R, double* t) {
     const int lane = threadIdx.x & 63;
-    const u64 gmask = mask & GROUND_MASK;
     const int n = popc64(gmask);
     if (n < 4) return false;
     int idx[4] = {0, 0, 0, 0};
@@ -521,6 +565,7 @@ __device__ bool pnp_ransac(u64 mask, const K4& k, const double* X, double u, dou
     double Hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Rh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, th[3] = {0, 0, 1};
     ok = ok && homography_4pt(s, d, Hh);
     ok = ok && pose_from_homography(Hh, k.fx, k.fy, k.cx, k.cy, Rh, th);
+    if (ok) polish4(Rh, th, k, s, d);
     int cnt = 0;
     double se = 0;
     for (u64 m = mask; m; m &= m - 1) {
@@ -534,11 +579,31 @@ __device__ bool pnp_ransac(u64 mask, const K4& k, const double* X, double u, dou
         }
     }
     const Best best = wave_best(Best{ok ? cnt : -1, ok ? se : INFINITY, lane});
-    if (best.cnt < 4) return false;
+    int best_cnt = best.cnt;
+    if (best.cnt >= 0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = bcast(Rh[i], best.h);
+        for (int i = 0; i < 9; ++i) R[i] = bcast(Rh[i], best.h);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = bcast(th[i], best.h);
+        for (int i = 0; i < 3; ++i) t[i] = bcast(th[i], best.h);
+    }
+    {   // hypothesis NH_PNP: least-squares homography over every z=0 point (stable when a 4-point sample is not)
+        double Hl[9], Rl[9], tl[3];
+        if (homography_lsq(gmask, X[0], X[1], u, v, 10, Hl) && pose_from_homography(Hl, k.fx, k.fy, k.cx, k.cy, Rl, tl)) {
+            refine_pose_lm(gmask, Rl, tl, k, X, u, v, 20, 1e-10);
+            double z;
+            const double e2 = reproj_e2(Rl, tl, k, X, u, v, &z);
+            const bool inl = ((mask >> lane) & 1) && e2 <= 64.0 && z > 1e-9;
+            const int c2 = popc64(__ballot(inl));
+            const double s2 = wsum(inl ? e2 : 0.0);
+            if (c2 > best_cnt || (c2 == best_cnt && s2 < best.s)) {
+                best_cnt = c2;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) R[i] = Rl[i];
+                t[0] = tl[0]; t[1] = tl[1]; t[2] = tl[2];
+            }
+        }
+    }
+    if (best_cnt < 4) return false;
     double z;
     const double e2 = reproj_e2(R, t, k, X, u, v, &z);
     const u64 inl = __ballot(((mask >> lane) & 1) && e2 <= 64.0 && z > 1e-9);
@@ -707,7 +772,7 @@ struct Pts {   // lane-local point data
 __device__ bool cam_solve_pnp(Cam& c, u64 mask, const Pts& p) {
     double R[9], t[3];
     const K4 k{c.fx, c.fy, c.cx, c.cy};
-    if (!pnp_ransac(mask, k, p.X64, p.u, p.v, R, t)) return false;
+    if (!pnp_ransac(mask, mask & GROUND_MASK, k, p.X64, p.u, p.v, R, t)) return false;
     cam_set_pose(c, R, t);
     return true;
 }
@@ -1012,45 +1077,9 @@ __global__ __launch_bounds__(64) void pnp_kernel(const double* __restrict__ Kin,
         for (int i = 0; i < 3; ++i) t[i] = -(R[i * 3] * pos[0] + R[i * 3 + 1] * pos[1] + R[i * 3 + 2] * pos[2]);
         refine_pose_lm(mask, R, t, k, X, u, v, max_iters, eps);
     } else {
-        // ground plane membership for the minimal solver = points with z == 0
+        // plane membership for the minimal solver = points with z == 0 (ids outside top_gates)
         const u64 gm = __ballot(in && X[2] == 0.0);
-        // pnp_ransac samples from (mask & GROUND_MASK); remap: run it on a mask whose ground subset is gm
-        const int ng = popc64(gm);
-        ok = ng >= 4;
-        if (ok) {
-            int idx[4] = {0, 0, 0, 0};
-            bool hok = sample4(lane, ng, idx);
-            double s[4][2], d[4][2];
-            for (int q = 0; q < 4; ++q) {
-                const int src = kth_set_bit(gm, idx[q]);
-                s[q][0] = __shfl(X[0], src, 64); s[q][1] = __shfl(X[1], src, 64);
-                d[q][0] = __shfl(u, src, 64); d[q][1] = __shfl(v, src, 64);
-            }
-            double Hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Rh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, th[3] = {0, 0, 1};
-            hok = hok && homography_4pt(s, d, Hh) && pose_from_homography(Hh, k.fx, k.fy, k.cx, k.cy, Rh, th);
-            int cnt = 0;
-            double se = 0;
-            for (u64 m = mask; m; m &= m - 1) {
-                const int j = __ffsll((long long)m) - 1;
-                const double Xj[3] = {bcast(X[0], j), bcast(X[1], j), bcast(X[2], j)};
-                const double uj = bcast(u, j), vj = bcast(v, j);
-                if (hok) {
-                    double z;
-                    const double e2 = reproj_e2(Rh, th, k, Xj, uj, vj, &z);
-                    if (e2 <= 64.0 && z > 1e-9) { ++cnt; se += e2; }
-                }
-            }
-            const Best best = wave_best(Best{hok ? cnt : -1, hok ? se : INFINITY, lane});
-            ok = best.cnt >= 4;
-            if (ok) {
-                for (int i = 0; i < 9; ++i) R[i] = bcast(Rh[i], best.h);
-                for (int i = 0; i < 3; ++i) t[i] = bcast(th[i], best.h);
-                double z;
-                const double e2 = reproj_e2(R, t, k, X, u, v, &z);
-                const u64 inl = __ballot(in && e2 <= 64.0 && z > 1e-9);
-                refine_pose_lm(inl, R, t, k, X, u, v, 20, 1e-10);
-            }
-        }
+        ok = pnp_ransac(mask, gm, k, X, u, v, R, t);
     }
     if (lane == 0 && ok) {
         for (int i = 0; i < 9; ++i) rt[b * 12 + i] = R[i];

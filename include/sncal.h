@@ -116,6 +116,19 @@ int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W,
                         float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes,
                         void* stream);
 
+/* Diagnostics (measurement only, no reference counterpart): per-kernel timing of forwards with HIP events
+ * recorded on the caller's stream between the plan's launches.  Enable, run forwards, then read the
+ * accumulated per-kernel-variant totals (the call synchronises the recorded events). */
+typedef struct {
+    char kernel[96];        /* e.g. "conv<bf16,k3,s1,NI4,MI6,G4>", "upsample_add", "softmax_nchw", "kp_decode" */
+    double flops;           /* algorithmic FLOPs (2*MACs of the direct formulation) summed over launches  */
+    double bytes;           /* algorithmic HBM bytes (inputs read once + outputs written once) summed     */
+    double ms;              /* summed event-to-event time                                                */
+    int launches;
+} sncal_kernel_stat;
+int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable);
+int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out, int cap, int* count);
+
 /* ------------------------------------------------------------------------------------------------
  * S0-S11  camera solve (batched, one wavefront per frame)
  * ---------------------------------------------------------------------------------------------- */

@@ -24,6 +24,12 @@ class HRNetDesc(ctypes.Structure):
                 ('num_channels', (ctypes.c_int * 4) * 3)]
 
 
+class KernelStat(ctypes.Structure):
+    """sncal_kernel_stat."""
+    _fields_ = [('kernel', ctypes.c_char * 96), ('flops', ctypes.c_double), ('bytes', ctypes.c_double),
+                ('ms', ctypes.c_double), ('launches', ctypes.c_int)]
+
+
 class Camera(ctypes.Structure):
     """sncal_camera."""
     _fields_ = [('position', ctypes.c_double * 3), ('rotation', ctypes.c_double * 9),
@@ -62,6 +68,8 @@ SIGNATURES = {
                                              ctypes.POINTER(ctypes.c_size_t)]),
     'sncal_hrnet_forward': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
                                            ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    'sncal_hrnet_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
+    'sncal_hrnet_get_profile': (ctypes.c_int, [vp, ctypes.POINTER(KernelStat), ctypes.c_int, c_int_p]),
     'sncal_pnp_refine_lm': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                            ctypes.c_double, vp]),
     'sncal_solve_pnp': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),

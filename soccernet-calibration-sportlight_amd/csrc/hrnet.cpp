@@ -86,6 +86,14 @@ struct sncal_hrnet {
     // cached per-(sb,H,W) layout
     int lay_sb = -1, lay_h = -1, lay_w = -1;
     size_t lay_bytes = 0;
+    // profiling (sncal_hrnet_set_profiling): events recorded between launches + what each interval ran
+    bool profiling = false;
+    struct Interval { hipEvent_t e0, e1; std::string kernel; double flops, bytes; };
+    std::vector<Interval> intervals;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::string last_kernel;
+    double last_flops = 0, last_bytes = 0;
 };
 
 namespace {
@@ -471,6 +479,14 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.tiles_y = (to.H + th - 1) / th;
     bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
+    if (net.profiling) {
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+                              bestv->ni, L.mi, L.g);
+        const double px = (double)sb * to.H * to.W;
+        net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
+        net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +
+                         (double)L.cout * L.cin * L.k * L.k * net.esize;
+    }
     return SNCAL_OK;
 }
 
@@ -506,6 +522,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); }
+    for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     delete net;
 }
 
@@ -575,6 +592,42 @@ extern "C" int sncal_hrnet_workspace(const sncal_hrnet* cnet, int B, int H, int 
     return SNCAL_OK;
 }
 
+namespace {
+hipEvent_t next_event(sncal_hrnet& net) {
+    if (net.events_used == net.event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        net.event_pool.push_back(e);
+    }
+    return net.event_pool[net.events_used++];
+}
+}  // namespace
+
+extern "C" int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_set_profiling: null");
+    net->profiling = enable != 0;
+    net->intervals.clear();
+    net->events_used = 0;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out, int cap, int* count) {
+    SNCAL_CHECK_ARG(net && count, "sncal_hrnet_get_profile: null");
+    std::map<std::string, sncal_kernel_stat> agg;
+    for (const auto& iv : net->intervals) {
+        SNCAL_CHECK_HIP(hipEventSynchronize(iv.e1));
+        float ms = 0;
+        SNCAL_CHECK_HIP(hipEventElapsedTime(&ms, iv.e0, iv.e1));
+        sncal_kernel_stat& st = agg[iv.kernel];
+        if (st.launches == 0) { memset(&st, 0, sizeof(st)); snprintf(st.kernel, sizeof(st.kernel), "%s", iv.kernel.c_str()); }
+        st.flops += iv.flops; st.bytes += iv.bytes; st.ms += ms; st.launches += 1;
+    }
+    *count = (int)agg.size();
+    int i = 0;
+    for (const auto& kv : agg) { if (out && i < cap) out[i] = kv.second; ++i; }
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
                                    int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_forward: null net");
@@ -595,7 +648,10 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
     for (int b0 = 0; b0 < B; b0 += SB) {
         const int sb = std::min(SB, B - b0);
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
+        hipEvent_t prev = nullptr;
+        if (net->profiling) { prev = next_event(*net); if (prev) SNCAL_CHECK_HIP(hipEventRecord(prev, stream)); }
         for (const Op& op : net->ops) {
+            net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             switch (op.type) {
                 case OP_INPUT:
                     rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
@@ -631,6 +687,30 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
                     break;
             }
             if (rc) return rc;
+            if (net->profiling && prev) {
+                if (net->last_kernel.empty()) {
+                    const char* names[] = {"nchw_to_nhwc", "conv", "upsample_add", "softmax_nchw", "kp_decode"};
+                    net->last_kernel = names[op.type];
+                    if (op.type == OP_UPADD) {
+                        const Tensor& to = net->tensors[op.out];
+                        double b = 0;
+                        for (int s2 = 0; s2 < op.nsrc; ++s2) { const Tensor& ts = net->tensors[op.srcs[s2]]; b += (double)sb * ts.H * ts.W * ts.C * net->esize; }
+                        const int C0 = op.nsrc ? net->tensors[op.srcs[0]].C : to.C;
+                        net->last_bytes = b + (double)sb * to.H * to.W * C0 * net->esize * (op.base >= 0 ? 2 : 1);
+                    } else if (op.type == OP_SOFTMAX || op.type == OP_DECODE) {
+                        net->last_bytes = (double)sb * C * th.H * th.W * 4 * (op.type == OP_SOFTMAX ? 2 : 1);
+                    } else if (op.type == OP_INPUT) {
+                        net->last_bytes = (double)sb * H * W * (3 * 4 + net->ge * net->esize);
+                    }
+                }
+                if (op.type == OP_DECODE && !d_kpts) continue;
+                hipEvent_t e1 = next_event(*net);
+                if (e1) {
+                    SNCAL_CHECK_HIP(hipEventRecord(e1, stream));
+                    net->intervals.push_back({prev, e1, net->last_kernel, net->last_flops, net->last_bytes});
+                    prev = e1;
+                }
+            }
         }
     }
     return SNCAL_OK;

@@ -174,6 +174,18 @@ class HRNetHeatmap:
                        'sncal_hrnet_forward')
         return heat, kpts
 
+    def set_profiling(self, enable: bool):
+        """Record HIP events between the plan's launches (measurement only)."""
+        _lib.check(self._L.sncal_hrnet_set_profiling(self._h, 1 if enable else 0), 'set_profiling')
+
+    def get_profile(self):
+        """[{kernel, flops, bytes, ms, launches}] accumulated since set_profiling(True) (synchronises)."""
+        n = ctypes.c_int()
+        buf = (_lib.KernelStat * 256)()
+        _lib.check(self._L.sncal_hrnet_get_profile(self._h, buf, 256, ctypes.byref(n)), 'get_profile')
+        return [dict(kernel=buf[i].kernel.decode(), flops=buf[i].flops, bytes=buf[i].bytes, ms=buf[i].ms,
+                     launches=buf[i].launches) for i in range(min(n.value, 256))]
+
     def __call__(self, x):
         """Reference nn.Module contract: list of stage outputs, [-1] is the head output."""
         return [self.forward(x, want_heat=True)[0]]

@@ -24,6 +24,13 @@
 //   - the weight chunk, already in fragment order [k-step][mi][lane][16 B] (lane-linear, conflict-free).
 // Each wave computes NI pixel fragments x MI channel fragments: per k-step MI + NI ds_read_b128 feed
 // MI*NI MFMAs.
+//
+// Staging is all LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction, no VGPR round trip): the
+// weight chunk is a lane-linear copy; the halo tile is written as [pixel][SLOTS x 16 B] where lanes that
+// fall on the pitch padding, outside the image or beyond Cin fetch out of bounds and the buffer descriptor
+// returns zeros -- zero padding costs nothing.  With STAGES == 2 the next chunk's DMA is issued right
+// after the single per-chunk barrier and lands while the current chunk's MFMAs run (one s_waitcnt
+// vmcnt(0) + s_barrier per chunk, raw barriers so that hipcc does not drain the DMA queue early).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -52,6 +59,7 @@ struct ConvParams {
     int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
     int tiles_x, tiles_y;
     int relu, out_f32;
+    unsigned w_bytes;                // size of the packed weight buffer (buffer descriptor range)
 };
 
 // pixel pitch (bytes) of the LDS halo tile that makes the B-fragment reads conflict-free
@@ -65,22 +73,28 @@ __host__ __device__ constexpr int halo_pitch(int G, int stride) {
 
 __host__ __device__ constexpr int conv_nks(int KS, int G) { return (KS * KS * G + 3) / 4; }
 
-inline size_t conv_lds_bytes(int KS, int S, int NI, int MI, int G, int twf) {
+inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
     const int th = 4 * NI / twf;
     const int hh = (th - 1) * S + KS, hw = (16 * twf - 1) * S + KS;
-    return (size_t)conv_nks(KS, G) * MI * 1024 + (size_t)hh * hw * halo_pitch(G, S);
+    const size_t halo = ((size_t)hh * hw * halo_pitch(G, S) + 1023) / 1024 * 1024;   // DMA writes whole KBs
+    return (size_t)conv_nks(KS, G) * MI * 1024 + halo;
+}
+inline size_t conv_lds_bytes(int KS, int S, int NI, int MI, int G, int twf, int stages) {
+    return conv_stage_bytes(KS, S, NI, MI, G, twf) * stages;
 }
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int STAGES>
 __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
     constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
     constexpr int PS = halo_pitch(G, STRIDE);
     constexpr int PAD = KS / 2;
+    constexpr int SLOTS = PS / 16;
+    constexpr int ESIZE = 16 / GE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;
-    char* s_in = smem + NKS * MI * 1024;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,6 +108,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     const int oy0 = ty * TH, ox0 = tx * 16 * TWF;
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
     const int g = lane >> 4, ln = lane & 15;
+    const int npix = HALO_H * HALO_W;
+    const int halo_bytes = (npix * PS + 1023) / 1024 * 1024;
+    const int stage_bytes = NKS * MI * 1024 + halo_bytes;
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -109,31 +126,54 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
         boff[j] = ((fr * STRIDE) * HALO_W + (fx * 16 + ln) * STRIDE) * PS;
     }
     const int row_pitch = HALO_W * PS;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const int npix = HALO_H * HALO_W;
 
-    for (int c = 0; c < p.cin_chunks; ++c) {
-        if (c > 0) __syncthreads();
-        {   // weight chunk: straight 16-B copy, already in fragment order
-            const uint4* wsrc = reinterpret_cast<const uint4*>(p.w) +
-                                ((size_t)nb * p.cin_chunks + c) * (NKS * MI * 64);
-            for (int i = tid; i < NKS * MI * 64; i += 256) reinterpret_cast<uint4*>(s_w)[i] = wsrc[i];
-        }
-        for (int i = tid; i < npix * G; i += 256) {   // halo tile, zero-filled outside the image / Cin
-            const int pix = i / G, cg = i - pix * G;
+    // buffer descriptors: one image of the input (so that ranges stay < 2 GB), the packed weights
+    const size_t img_bytes = (size_t)p.Hin * p.Win * p.Cin * ESIZE;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int n_halo_instr = halo_bytes / 1024;
+
+    auto issue_chunk = [&](int c, int stage) {
+        char* st = smem + stage * stage_bytes;
+        // weights: lane-linear 1 KB pieces, round-robin over the 4 waves
+        const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * (NKS * MI * 1024));
+        for (int i = wave; i < NKS * MI; i += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
+        // halo: slot s of the [pixel][SLOTS] image; padding slots / outside-image pixels / channels >= Cin read
+        // out of range and come back as zeros
+        char* sh = st + NKS * MI * 1024;
+        const unsigned cbase = (unsigned)(c * G * 16);
+        for (int j = wave; j < n_halo_instr; j += 4) {
+            const int slot = j * 64 + lane;
+            const int pix = slot / SLOTS, cg = slot - pix * SLOTS;
             const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            const int iy = iy0 + hy, ix = ix0 + hx, ch = (c * G + cg) * GE;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ch < p.Cin)
-                v = *reinterpret_cast<const uint4*>(in + (((size_t)n * p.Hin + iy) * p.Win + ix) * p.Cin + ch);
-            *reinterpret_cast<uint4*>(s_in + pix * PS + cg * 16) = v;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
+                            (c * G + cg) * GE < p.Cin;
+            const unsigned voff = ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(sh + j * 1024), 16, voff, cbase, 0, 0);
         }
-        __syncthreads();
+    };
+
+    if constexpr (STAGES == 2) issue_chunk(0, 0);
+    for (int c = 0; c < p.cin_chunks; ++c) {
+        const int stage = STAGES == 2 ? (c & 1) : 0;
+        if constexpr (STAGES == 1) {
+            if (c > 0) asm volatile("s_barrier" ::: "memory");        // everyone finished reading the stage
+            issue_chunk(c, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my pieces of chunk c have landed
+        asm volatile("s_barrier" ::: "memory");                       // ... everyone's, and compute(c-1) is over
+        if constexpr (STAGES == 2) {
+            if (c + 1 < p.cin_chunks) issue_chunk(c + 1, stage ^ 1);  // lands while chunk c computes
+        }
+        const char* s_w = smem + stage * stage_bytes;
+        const char* s_in = s_w + NKS * MI * 1024;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             int off;
             if constexpr (G % 4 == 0) {          // the 4 k-groups of a k-step share one tap
-                constexpr int dummy = 0; (void)dummy;
                 const int tap = (4 * s) / G, cg0 = (4 * s) % G;
                 off = (tap / KS) * row_pitch + (tap % KS) * PS + (cg0 + g) * 16;
             } else {
@@ -212,18 +252,18 @@ typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
-    ConvLaunchFn launch;
+    ConvLaunchFn launch1, launch2;   // single-stage / double-buffered (chunk c+1 DMA under chunk c MFMAs)
 };
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int STAGES>
 void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, STAGES>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

@@ -315,9 +315,11 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
     const int ge = net.ge;
     const int cout_frags = (L.cout + 15) / 16;
     double best = -1;
+    static const int force_mi = getenv("SNCAL_FORCE_MI") ? atoi(getenv("SNCAL_FORCE_MI")) : 0;   // tuning aid
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride) continue;
+        if (force_mi && L.k == 3 && L.stride == 1 && V.mi != force_mi && cout_frags % force_mi == 0) continue;
         const int chunks = (L.cin_phys + V.g * ge - 1) / (V.g * ge);
         const int nks = conv_nks(V.ks, V.g);
         const double k_eff = (double)(L.k * L.k * L.cin_phys / ge) / (double)(chunks * nks * 4);
@@ -452,24 +454,35 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.Hout = to.H; p.Wout = to.W; p.cout_frags = L.cout_frags; p.cout = L.cout;
     p.out_cstride = to.C; p.out_coff = op.out_coff;
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
-    // pick NI / tile shape for this spatial size
+    // pick NI / tile shape / staging depth for this spatial size
     const ConvVariant* bestv = nullptr;
-    int best_twf = 1; double best_score = -1; size_t best_lds = 0;
+    int best_twf = 1, best_stages = 1; double best_score = -1; size_t best_lds = 0;
+    static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
+    static const int force_st = getenv("SNCAL_FORCE_STAGES") ? atoi(getenv("SNCAL_FORCE_STAGES")) : 0;
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride || V.mi != L.mi || V.g != L.g) continue;
+        if (force_ni && L.k == 3 && L.stride == 1 && V.ni != force_ni) continue;
         const int F = 4 * V.ni;
         for (int twf = 1; twf <= F; twf *= 2) {
             const int th = F / twf;
-            const size_t lds = conv_lds_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
-            if (lds > 160 * 1024) continue;
-            const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
-            const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
-            const long blocks = ty * tx * sb * L.nblk;
-            const double fill = std::min(1.0, (double)blocks / 256.0);        // at least one workgroup per CU
-            const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
-            const double score = eff * (0.3 + 0.7 * fill) * (0.4 + 0.6 * reuse / 2.4);
-            if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; }
+            const size_t stage = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
+            for (int stages = 1; stages <= 2; ++stages) {
+                if (stages == 2 && L.chunks < 2) continue;
+                if (force_st && stages != force_st && !(force_st == 2 && L.chunks < 2)) continue;
+                const size_t lds = stage * stages;
+                if (lds > 160 * 1024) continue;
+                const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
+                const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
+                const long blocks = ty * tx * sb * L.nblk;
+                const double fill = std::min(1.0, (double)blocks / 256.0);        // at least one workgroup per CU
+                const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
+                const int per_cu = (int)std::min<size_t>(2, (160 * 1024) / lds);
+                // overlap of staging with MFMA: explicit (2 stages) or through a second resident workgroup
+                const double overlap = stages == 2 ? 1.0 : (per_cu >= 2 ? 0.8 : 0.55);
+                const double score = eff * (0.3 + 0.7 * fill) * (0.4 + 0.6 * reuse / 2.4) * overlap;
+                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; best_stages = stages; }
+            }
         }
     }
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
@@ -477,11 +490,12 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.twf = best_twf;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;
-    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
+    (best_stages == 2 ? bestv->launch2 : bestv->launch1)(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
-                              bestv->ni, L.mi, L.g);
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,ST%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+                              bestv->ni, L.mi, L.g, best_stages);
         const double px = (double)sb * to.H * to.W;
         net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
         net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +

@@ -16,9 +16,17 @@ x = torch.rand((B, 3, 540, 960), device=dev)
 for _ in range(1):
     net.forward(x, want_heat=False, decode_size=(540, 960))
 torch.cuda.synchronize()
+net.set_profiling(True)
 t0 = time.time()
 for _ in range(steps):
     net.forward(x, want_heat=False, decode_size=(540, 960))
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 print(f'B={B} {dtype} subbatch={os.environ.get("SNCAL_SUBBATCH", "8")}: {dt*1e3:.1f} ms/step, {B/dt:.1f} frames/s, {B/dt*507.82e9/1e12:.1f} TFLOP/s (reference-formulation flops)')
+
+prof = sorted(net.get_profile(), key=lambda p: -p['ms'])
+tot = sum(p['ms'] for p in prof)
+for p in prof[:14]:
+    tf = p['flops'] / (p['ms'] * 1e-3) / 1e12 if p['ms'] else 0
+    gbs = p['bytes'] / (p['ms'] * 1e-3) / 1e9 if p['ms'] else 0
+    print(f"  {p['ms']/tot*100:5.1f}%  {p['ms']/steps:8.2f} ms/step  n={p['launches']//steps:4d}  {tf:7.1f} TF  {gbs:7.0f} GB/s  {p['kernel']}")

@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "conv.hpp"
 #include "ops.hpp"
+#include "head.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -40,9 +41,13 @@ struct ConvLayer {
     int cin_phys = 0, mi = 0, g = 0, chunks = 0, nblk = 0, cout_frags = 0;
     void* d_w = nullptr;
     float* d_bias = nullptr;
+    // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
+    bool derived = false;
+    int col_off = 0;
 };
 
-enum OpType { OP_INPUT, OP_CONV, OP_UPADD, OP_SOFTMAX, OP_DECODE };
+enum OpType { OP_INPUT, OP_CONV, OP_UPADD, OP_SOFTMAX, OP_DECODE, OP_HEAD };
+enum OpGroup { GRP_ALL = 0, GRP_UNFUSED = 1, GRP_FUSED = 2 };   // head variants living side by side in the plan
 
 struct Op {
     OpType type;
@@ -53,6 +58,8 @@ struct Op {
     bool out_f32 = false;
     int base = -1, srcs[3] = {-1, -1, -1}, nsrc = 0;
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
+    int group = GRP_ALL;
+    int head_direct = -1, head_src[HEAD_MAX_SRC] = {-1, -1, -1, -1, -1}, head_nsrc = 0;   // OP_HEAD
 };
 
 struct Tensor {
@@ -79,6 +86,14 @@ struct sncal_hrnet {
     std::vector<Op> ops;
     std::vector<Tensor> tensors;
     int t_heat = -1, t_kpts_src = -1;
+    int n_public = 0;                 // layers [0, n_public) are the reference's convs; the rest are internal
+    int t_stem = -1, t_branch0 = -1;  // tensors whose dims decide whether the fused head applies
+    int l_head0 = -1, l_head1 = -1;   // last_layer.0 / last_layer.3
+    int head_direct_coff = 0, head_direct_c = 0, head_hp = 0, head_m2 = 0;
+    bool fused_enabled = true, use_fused = false;
+    void *d_hw0 = nullptr, *d_hw1 = nullptr;
+    float *d_hb0 = nullptr, *d_hb1 = nullptr;
+    int cur_group = GRP_ALL;
     bool finalized = false;
     int subbatch = 32;
     const ConvVariant* variants = nullptr;
@@ -128,6 +143,7 @@ struct Builder {
         if (it == net.layer_by_name.end()) { set_error("internal: conv %s not enumerated", name.c_str()); return -1; }
         const ConvLayer& L = net.layers[it->second];
         Op op; op.type = OP_CONV; op.conv = it->second; op.in = in; op.res = res; op.relu = relu; op.out_f32 = out_f32;
+        op.group = net.cur_group;
         const int cphys = out_f32 ? ((L.cout + 15) / 16) * 16 : L.cout;
         op.out = new_tensor(cphys, out_f32);
         net.ops.push_back(op);
@@ -142,7 +158,7 @@ struct Builder {
     }
     void concat_part(int cat, int src, int coff, int dims_from, int dims_mul) {
         Op op; op.type = OP_UPADD; op.base = -1; op.nsrc = 1; op.srcs[0] = src; op.out = cat; op.out_coff = coff;
-        op.dims_from = dims_from; op.dims_mul = dims_mul;
+        op.dims_from = dims_from; op.dims_mul = dims_mul; op.group = net.cur_group;
         net.ops.push_back(op);
     }
 
@@ -284,16 +300,40 @@ struct Builder {
             }
             ys = xs;
         }
-        // head: upsample + concat (hrnet.py:489-509; line/hrnet.py:236-245)
+        // head, reference formulation: upsample + concat + two 1x1 convs (hrnet.py:489-510; line/hrnet.py:236-248)
+        net.n_public = (int)net.layers.size();
+        net.t_stem = t_stem; net.t_branch0 = ys[0];
+        net.l_head0 = net.layer_by_name[P + "last_layer.0"]; net.l_head1 = net.layer_by_name[P + "last_layer.3"];
         int catC = 0;
         for (int t : ys) catC += net.tensors[t].C;
         if (d.upscale > 1) catC += d.stem_width;
+        net.cur_group = GRP_UNFUSED;
         const int cat = new_tensor(catC);
         int coff = 0;
         if (d.upscale > 1) { concat_part(cat, t_stem, coff, ys[0], d.upscale); coff += d.stem_width; }
         for (int t : ys) { concat_part(cat, t, coff, ys[0], d.upscale); coff += net.tensors[t].C; }
         const int hid = conv(P + "last_layer.0", cat, true);
         const int logits = conv(P + "last_layer.3", hid, false, -1, true);
+        // head, fused formulation (head.hip): per-branch 1x1 products at native resolution + one fused kernel
+        net.cur_group = GRP_FUSED;
+        net.head_hp = ((catC + 31) / 32) * 32;
+        net.head_m2 = (d.num_classes + 15) / 16;
+        {
+            Op hop; hop.type = OP_HEAD; hop.group = GRP_FUSED; hop.out = logits;
+            int col = 0;
+            std::vector<int> gathered;
+            if (d.upscale > 1) { hop.head_direct = t_stem; net.head_direct_coff = 0; net.head_direct_c = d.stem_width; col = d.stem_width; gathered = ys; }
+            else { hop.head_direct = ys[0]; net.head_direct_coff = 0; net.head_direct_c = net.tensors[ys[0]].C; col = net.head_direct_c; gathered.assign(ys.begin() + 1, ys.end()); }
+            for (int t : gathered) {
+                const std::string nm = fmt("head.t%d", hop.head_nsrc);
+                const int li = add_layer(nm, "", net.tensors[t].C, net.head_hp, 1, 1, false);
+                net.layers[li].derived = true; net.layers[li].col_off = col;
+                col += net.tensors[t].C;
+                hop.head_src[hop.head_nsrc++] = conv(nm, t, false);
+            }
+            net.ops.push_back(hop);
+        }
+        net.cur_group = GRP_ALL;
         { Op op; op.type = OP_SOFTMAX; op.in = logits; op.out = new_tensor(d.num_classes, true);
           net.tensors[op.out].external_heat = true; net.t_heat = op.out; net.ops.push_back(op); }
         { Op op; op.type = OP_DECODE; op.in = net.t_heat; net.ops.push_back(op); }
@@ -378,11 +418,82 @@ int pack_layer(sncal_hrnet& net, ConvLayer& L) {
     return SNCAL_OK;
 }
 
+// stage-1 / stage-2 A fragments + biases of the fused head (head.hip), bf16 only
+int pack_head(sncal_hrnet& net) {
+    if (net.dtype != SNCAL_BF16) return SNCAL_OK;
+    const ConvLayer& H0 = net.layers[net.l_head0];
+    const ConvLayer& H1 = net.layers[net.l_head1];
+    if (!H1.is_set) { set_error("conv %s has no weights", H1.name.c_str()); return SNCAL_ERR_STATE; }
+    const int HP = net.head_hp, NQ = HP / 32, M2 = net.head_m2, Cd = net.head_direct_c, coff = net.head_direct_coff;
+    if (Cd > 64 || M2 > 4) return SNCAL_OK;      // fused kernel does not apply; the reference formulation is used
+    std::vector<uint16_t> w0((size_t)NQ * 2 * 2 * 64 * 8, 0), w1((size_t)NQ * M2 * 64 * 8, 0);
+    std::vector<float> b0(HP, 0.f), b1((size_t)M2 * 16, 0.f);
+    for (int q = 0; q < NQ; ++q)
+        for (int f = 0; f < 2; ++f)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane & 15, gk = lane >> 4;
+                    const int ch = q * 32 + (m >> 2) * 8 + f * 4 + (m & 3);      // row permutation, see head.hip
+                    if (ch >= H0.cout) continue;
+                    uint16_t* dst = w0.data() + ((((size_t)(q * 2 + f) * 2 + ks) * 64) + lane) * 8;
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ks * 32 + gk * 8 + e;
+                        if (k < Cd) dst[e] = f2bf(H0.w[(size_t)ch * H0.cin + coff + k] * H0.scale[ch]);
+                    }
+                }
+    for (int co = 0; co < H0.cout; ++co) b0[co] = H0.shift[co];
+    for (int q = 0; q < NQ; ++q)
+        for (int mi = 0; mi < M2; ++mi)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int cls = mi * 16 + (lane & 15), gk = lane >> 4;
+                if (cls >= H1.cout) continue;
+                uint16_t* dst = w1.data() + (((size_t)(q * M2 + mi) * 64) + lane) * 8;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = q * 32 + gk * 8 + e;
+                    if (k < H1.cin) dst[e] = f2bf(H1.w[(size_t)cls * H1.cin + k] * H1.scale[cls]);
+                }
+            }
+    for (int c = 0; c < H1.cout; ++c) b1[c] = H1.shift[c];
+    for (void** q : {&net.d_hw0, &net.d_hw1}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    if (net.d_hb0) { (void)hipFree(net.d_hb0); net.d_hb0 = nullptr; }
+    if (net.d_hb1) { (void)hipFree(net.d_hb1); net.d_hb1 = nullptr; }
+    SNCAL_CHECK_HIP(hipMalloc(&net.d_hw0, w0.size() * 2));
+    SNCAL_CHECK_HIP(hipMalloc(&net.d_hw1, w1.size() * 2));
+    SNCAL_CHECK_HIP(hipMalloc((void**)&net.d_hb0, b0.size() * 4));
+    SNCAL_CHECK_HIP(hipMalloc((void**)&net.d_hb1, b1.size() * 4));
+    SNCAL_CHECK_HIP(hipMemcpy(net.d_hw0, w0.data(), w0.size() * 2, hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(net.d_hw1, w1.data(), w1.size() * 2, hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(net.d_hb0, b0.data(), b0.size() * 4, hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(net.d_hb1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+    return SNCAL_OK;
+}
+
 // shape inference + workspace layout for a sub-batch of `sb` frames of HxW
+inline bool op_active(const sncal_hrnet& net, const Op& op) {
+    return op.group == GRP_ALL || (op.group == GRP_FUSED) == net.use_fused;
+}
+
 int layout(sncal_hrnet& net, int sb, int H, int W) {
     if (net.lay_sb == sb && net.lay_h == H && net.lay_w == W) return SNCAL_OK;
     std::vector<Tensor>& T = net.tensors;
+    {   // does the fused head apply?  (bf16 path; the direct tensor must already sit at head resolution)
+        auto half = [](int v) { return (v + 2 - 3) / 2 + 1; };
+        const int sh = half(H), sw = half(W), bh = half(sh), bw = half(sw);
+        const bool dims_ok = net.desc.upscale == 1 || (sh == bh * net.desc.upscale && sw == bw * net.desc.upscale);
+        net.use_fused = net.fused_enabled && net.dtype == SNCAL_BF16 && dims_ok && net.d_hw0 != nullptr;
+    }
+    for (Tensor& t : T) { t.first = -1; t.last = -1; }
+    for (size_t i = 0; i < net.ops.size(); ++i) {       // lifetimes over the active ops
+        const Op& op = net.ops[i];
+        if (!op_active(net, op)) continue;
+        auto use = [&](int t) { if (t >= 0) T[t].last = std::max(T[t].last, (int)i); };
+        use(op.in); use(op.res); use(op.base); use(op.dims_from); use(op.head_direct);
+        for (int s2 = 0; s2 < op.nsrc; ++s2) use(op.srcs[s2]);
+        for (int s2 = 0; s2 < op.head_nsrc; ++s2) use(op.head_src[s2]);
+        if (op.out >= 0) { if (T[op.out].first < 0) T[op.out].first = (int)i; T[op.out].last = std::max(T[op.out].last, (int)i); }
+    }
     for (const Op& op : net.ops) {
+        if (!op_active(net, op)) continue;
         switch (op.type) {
             case OP_INPUT: T[op.out].H = H; T[op.out].W = W; break;
             case OP_CONV: {
@@ -397,6 +508,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
                 else { T[op.out].H = T[op.dims_from].H * op.dims_mul; T[op.out].W = T[op.dims_from].W * op.dims_mul; }
                 break;
             case OP_SOFTMAX: T[op.out].H = T[op.in].H; T[op.out].W = T[op.in].W; break;
+            case OP_HEAD: T[op.out].H = T[op.head_direct].H; T[op.out].W = T[op.head_direct].W; break;
             case OP_DECODE: break;
         }
     }
@@ -478,8 +590,9 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
                 const double fill = std::min(1.0, (double)blocks / 256.0);        // at least one workgroup per CU
                 const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
                 const int per_cu = (int)std::min<size_t>(2, (160 * 1024) / lds);
-                // overlap of staging with MFMA: explicit (2 stages) or through a second resident workgroup
-                const double overlap = stages == 2 ? 1.0 : (per_cu >= 2 ? 0.8 : 0.55);
+                // overlap of staging with MFMA.  Measured on MI355X (profiles/): a second resident workgroup (2 waves
+                // per SIMD, single stage) beats explicit double buffering at one workgroup per CU by ~1.4x.
+                const double overlap = stages == 1 ? (per_cu >= 2 ? 1.0 : 0.6) : 0.75;
                 const double score = eff * (0.3 + 0.7 * fill) * (0.4 + 0.6 * reuse / 2.4) * overlap;
                 if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; best_stages = stages; }
             }
@@ -527,6 +640,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
     net->esize = dtype == SNCAL_BF16 ? 2 : 4;
     net->variants = dtype == SNCAL_BF16 ? conv_variants_bf16(&net->nvariants) : conv_variants_f32(&net->nvariants);
     if (const char* e = getenv("SNCAL_SUBBATCH")) { const int v = atoi(e); if (v > 0) net->subbatch = v; }
+    if (const char* e = getenv("SNCAL_FUSED_HEAD")) net->fused_enabled = atoi(e) != 0;
     Builder b(*net);
     if (!b.build()) { delete net; return SNCAL_ERR_STATE; }
     *out = net;
@@ -537,14 +651,15 @@ extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
+    for (void* q : {net->d_hw0, net->d_hw1, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
 }
 
-extern "C" int sncal_hrnet_num_convs(const sncal_hrnet* net) { return net ? (int)net->layers.size() : 0; }
+extern "C" int sncal_hrnet_num_convs(const sncal_hrnet* net) { return net ? net->n_public : 0; }
 
 extern "C" int sncal_hrnet_conv_info(const sncal_hrnet* net, int idx, char* name, int name_cap, char* bn_name, int bn_cap,
                                      int* cin, int* cout, int* ksize, int* stride, int* has_bias) {
-    SNCAL_CHECK_ARG(net && idx >= 0 && idx < (int)net->layers.size(), "sncal_hrnet_conv_info: index %d", idx);
+    SNCAL_CHECK_ARG(net && idx >= 0 && idx < net->n_public, "sncal_hrnet_conv_info: index %d", idx);
     const ConvLayer& L = net->layers[idx];
     if (name && name_cap > 0) snprintf(name, name_cap, "%s", L.name.c_str());
     if (bn_name && bn_cap > 0) snprintf(bn_name, bn_cap, "%s", L.bn.c_str());
@@ -557,7 +672,7 @@ extern "C" int sncal_hrnet_conv_info(const sncal_hrnet* net, int idx, char* name
 }
 
 extern "C" int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_weight, const float* h_scale, const float* h_shift) {
-    SNCAL_CHECK_ARG(net && idx >= 0 && idx < (int)net->layers.size(), "sncal_hrnet_set_conv: index %d", idx);
+    SNCAL_CHECK_ARG(net && idx >= 0 && idx < net->n_public, "sncal_hrnet_set_conv: index %d", idx);
     SNCAL_CHECK_ARG(h_weight && h_shift, "sncal_hrnet_set_conv: null weights");
     ConvLayer& L = net->layers[idx];
     const size_t nw = (size_t)L.cout * L.cin * L.k * L.k;
@@ -575,6 +690,22 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
     // physical Cin of every conv = channel count of its input tensor
     for (const Op& op : net->ops)
         if (op.type == OP_CONV) net->layers[op.conv].cin_phys = net->tensors[op.in].C;
+    {   // internal layers of the fused head are slices of last_layer.0 (BN scale folded, no shift)
+        const ConvLayer& H0 = net->layers[net->l_head0];
+        if (!H0.is_set) { set_error("conv %s has no weights", H0.name.c_str()); return SNCAL_ERR_STATE; }
+        for (ConvLayer& L : net->layers) {
+            if (!L.derived) continue;
+            L.w.assign((size_t)L.cout * L.cin, 0.f);
+            L.scale.assign(L.cout, 1.f); L.shift.assign(L.cout, 0.f);
+            for (int co = 0; co < H0.cout; ++co) {
+                L.scale[co] = H0.scale[co];
+                for (int ci = 0; ci < L.cin; ++ci) L.w[(size_t)co * L.cin + ci] = H0.w[(size_t)co * H0.cin + L.col_off + ci];
+            }
+            L.is_set = true;
+        }
+        const int rc = pack_head(*net);
+        if (rc) return rc;
+    }
     for (ConvLayer& L : net->layers) {
         if (!L.is_set) { set_error("conv %s has no weights", L.name.c_str()); return SNCAL_ERR_STATE; }
         choose_packing(*net, L);
@@ -665,6 +796,7 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
         hipEvent_t prev = nullptr;
         if (net->profiling) { prev = next_event(*net); if (prev) SNCAL_CHECK_HIP(hipEventRecord(prev, stream)); }
         for (const Op& op : net->ops) {
+            if (!op_active(*net, op)) continue;
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             switch (op.type) {
                 case OP_INPUT:
@@ -696,6 +828,32 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
                                              (size_t)tl.H * tl.W, net->desc.head_softmax ? 0 : 1, heat, stream);
                     break;
                 }
+                case OP_HEAD: {
+                    const Tensor& td = net->tensors[op.head_direct];
+                    const Tensor& to = net->tensors[op.out];
+                    HeadParams hp;
+                    memset(&hp, 0, sizeof(hp));
+                    hp.direct = ws + td.offset; hp.Cd = td.C;
+                    hp.w0 = net->d_hw0; hp.bias0 = net->d_hb0; hp.w1 = net->d_hw1; hp.bias1 = net->d_hb1;
+                    hp.nsrc = op.head_nsrc;
+                    for (int s2 = 0; s2 < op.head_nsrc; ++s2) {
+                        const Tensor& ts = net->tensors[op.head_src[s2]];
+                        hp.src[s2] = ws + ts.offset; hp.Hs[s2] = ts.H; hp.Ws[s2] = ts.W;
+                        hp.sy[s2] = to.H > 1 ? (float)(ts.H - 1) / (float)(to.H - 1) : 0.f;
+                        hp.sx[s2] = to.W > 1 ? (float)(ts.W - 1) / (float)(to.W - 1) : 0.f;
+                    }
+                    hp.logits = reinterpret_cast<float*>(ws + to.offset);
+                    hp.N = sb; hp.H = to.H; hp.W = to.W; hp.HP = net->head_hp; hp.NQ = net->head_hp / 32; hp.LC = to.C;
+                    rc = launch_head_fused(hp, net->head_m2, stream);
+                    if (net->profiling) {
+                        net->last_kernel = "head_fused";
+                        const double px = (double)sb * to.H * to.W;
+                        net->last_flops = 2.0 * px * net->head_hp * (td.C + net->head_m2 * 16);
+                        net->last_bytes = px * (td.C * 2 + to.C * 4);
+                        for (int s2 = 0; s2 < op.head_nsrc; ++s2) { const Tensor& ts = net->tensors[op.head_src[s2]]; net->last_bytes += (double)sb * ts.H * ts.W * ts.C * 2; }
+                    }
+                    break;
+                }
                 case OP_DECODE:
                     if (d_kpts) rc = sncal_heatmap_decode(heat, sb, C, th.H, th.W, img_h, img_w, d_kpts + (size_t)b0 * (C - 1) * 3, stream_);
                     break;
@@ -703,7 +861,7 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
             if (rc) return rc;
             if (net->profiling && prev) {
                 if (net->last_kernel.empty()) {
-                    const char* names[] = {"nchw_to_nhwc", "conv", "upsample_add", "softmax_nchw", "kp_decode"};
+                    const char* names[] = {"nchw_to_nhwc", "conv", "upsample_add", "softmax_nchw", "kp_decode", "head_fused"};
                     net->last_kernel = names[op.type];
                     if (op.type == OP_UPADD) {
                         const Tensor& to = net->tensors[op.out];

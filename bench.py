@@ -126,15 +126,14 @@ def main():
     rec_bytes = ctypes.sizeof(sncal_amd._lib.Camera)
     rec_net = torch.empty((B, rec_bytes), dtype=torch.uint8, device=dev)
     rec_syn = torch.empty((B, rec_bytes), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * B, 57 * 3 * 4 + 2 * rec_bytes), dtype=torch.uint8, device=dev) if world > 1 else None
+    from sncal_amd.dist import pack_records, gather_records
 
     def step():
         _, kpts = net.forward(x, want_heat=False, decode_size=(540, 960))
         cc.solve_device(kpts, out=rec_net)
         cc.solve_device(kp_synth, out=rec_syn)
         if world > 1:   # the single collective of the path: per-frame records to every rank (RCCL over xGMI)
-            local_rec = torch.cat([kpts.view(torch.uint8).reshape(B, -1), rec_net, rec_syn], dim=1).contiguous()
-            dist.all_gather_into_tensor(gathered, local_rec)
+            gather_records(pack_records(kpts, rec_net, rec_syn))
         return kpts
 
     def fence():

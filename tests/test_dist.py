@@ -1,0 +1,56 @@
+"""CPU, world_size 2, gloo: the multi-GPU path (frame sharding + the single all_gather of result records)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, n_frames, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sncal_amd
+    from sncal_amd.dist import shard_range, pack_records, gather_records
+    start, stop = shard_range(n_frames, rank, world)
+    counts = [shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0] for r in range(world)]
+    # every rank "computes" records for its own frames only: frame id encoded in the payload
+    ids = torch.arange(start, stop)
+    kpts = ids.float()[:, None, None].expand(-1, 57, 3).contiguous() + 0.25
+    rec = (ids % 251).to(torch.uint8)[:, None].expand(-1, 136).contiguous()
+    allrec = gather_records(pack_records(kpts, rec), counts)
+    ok = allrec.shape == (n_frames, 57 * 3 * 4 + 136)
+    k_all = allrec[:, :684].contiguous().view(torch.float32).reshape(n_frames, 57, 3)
+    ok = ok and torch.equal(k_all[:, 0, 0], torch.arange(n_frames).float() + 0.25)
+    ok = ok and torch.equal(allrec[:, 684], (torch.arange(n_frames) % 251).to(torch.uint8))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_frames, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, n_frames, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def test_shard_ranges_cover_all_frames():
+    import sncal_amd
+    from sncal_amd.dist import shard_range
+    for n in (0, 1, 7, 64, 512, 1025):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_world2_even():
+    assert _run(128) == {0: True, 1: True}
+
+
+def test_gather_world2_ragged():
+    assert _run(37) == {0: True, 1: True}

@@ -34,7 +34,7 @@ def build(verbose=False, force=False, jobs=None):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h', '.inc'))]
     hdrs.append(os.path.join(os.path.dirname(PKG), 'include', 'sncal.h'))
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []

@@ -28,9 +28,12 @@
 // Staging is all LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction, no VGPR round trip): the
 // weight chunk is a lane-linear copy; the halo tile is written as [pixel][SLOTS x 16 B] where lanes that
 // fall on the pitch padding, outside the image or beyond Cin fetch out of bounds and the buffer descriptor
-// returns zeros -- zero padding costs nothing.  With STAGES == 2 the next chunk's DMA is issued right
-// after the single per-chunk barrier and lands while the current chunk's MFMAs run (one s_waitcnt
-// vmcnt(0) + s_barrier per chunk, raw barriers so that hipcc does not drain the DMA queue early).
+// returns zeros -- zero padding costs nothing.  Barriers are raw s_barrier + explicit s_waitcnt vmcnt so
+// that hipcc does not drain the DMA queue early.  Measured on MI355X the kernel is bound by the LDS-fill
+// rate (L2 -> LDS, ~5.7 TB/s chip-wide) and most of the fill is the weight chunk that every workgroup
+// re-reads, so a workgroup can walk NT vertically stacked sub-tiles per weight chunk (NT accumulator sets,
+// one halo buffer): the weight bytes per output pixel drop by NT.  Staging/MFMA overlap comes from a
+// second resident workgroup per CU (explicit double buffering at one workgroup per CU measured 1.4x slower).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -60,6 +63,8 @@ struct ConvParams {
     int tiles_x, tiles_y;
     int relu, out_f32;
     unsigned w_bytes;                // size of the packed weight buffer (buffer descriptor range)
+    int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA (results invalid)
+    int epi_lds;                     // 1: transpose the output tile through LDS for 16-byte coalesced stores
 };
 
 // pixel pitch (bytes) of the LDS halo tile that makes the B-fragment reads conflict-free
@@ -79,14 +84,12 @@ inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
     const size_t halo = ((size_t)hh * hw * halo_pitch(G, S) + 1023) / 1024 * 1024;   // DMA writes whole KBs
     return (size_t)conv_nks(KS, G) * MI * 1024 + halo;
 }
-inline size_t conv_lds_bytes(int KS, int S, int NI, int MI, int G, int twf, int stages) {
-    return conv_stage_bytes(KS, S, NI, MI, G, twf) * stages;
-}
+
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int STAGES>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int NT>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
     constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
@@ -105,18 +108,20 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     const int nb = blockIdx.y;
     const int TWF = p.twf, TH = 4 * NI / TWF;
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
-    const int oy0 = ty * TH, ox0 = tx * 16 * TWF;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    const int oy00 = ty * TH * NT, ox0 = tx * 16 * TWF;       // NT sub-tiles stacked in y
+    const int ix0 = ox0 * STRIDE - PAD;
     const int g = lane >> 4, ln = lane & 15;
     const int npix = HALO_H * HALO_W;
     const int halo_bytes = (npix * PS + 1023) / 1024 * 1024;
     const int stage_bytes = NKS * MI * 1024 + halo_bytes;
 
-    f32x4 acc[MI][NI];
+    f32x4 acc[NT][MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[t][mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int boff[NI];
 #pragma unroll
@@ -134,15 +139,15 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int n_halo_instr = halo_bytes / 1024;
 
-    auto issue_chunk = [&](int c, int stage) {
-        char* st = smem + stage * stage_bytes;
-        // weights: lane-linear 1 KB pieces, round-robin over the 4 waves
+    char* const s_w = smem;
+    char* const s_in = smem + NKS * MI * 1024;
+    auto issue_weights = [&](int c) {        // lane-linear 1 KB pieces, round-robin over the 4 waves
         const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * (NKS * MI * 1024));
         for (int i = wave; i < NKS * MI; i += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(st + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
-        // halo: slot s of the [pixel][SLOTS] image; padding slots / outside-image pixels / channels >= Cin read
-        // out of range and come back as zeros
-        char* sh = st + NKS * MI * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(s_w + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
+    };
+    auto issue_halo = [&](int c, int t) {    // slot s of the [pixel][SLOTS] image; padding slots / outside-image
+        const int iy0 = (oy00 + t * TH) * STRIDE - PAD;   // pixels read out of range and come back as zeros
         const unsigned cbase = (unsigned)(c * G * 16);
         for (int j = wave; j < n_halo_instr; j += 4) {
             const int slot = j * 64 + lane;
@@ -152,65 +157,135 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
                             (c * G + cg) * GE < p.Cin;
             const unsigned voff = ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(sh + j * 1024), 16, voff, cbase, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(s_in + j * 1024), 16, voff, cbase, 0, 0);
         }
     };
 
-    if constexpr (STAGES == 2) issue_chunk(0, 0);
     for (int c = 0; c < p.cin_chunks; ++c) {
-        const int stage = STAGES == 2 ? (c & 1) : 0;
-        if constexpr (STAGES == 1) {
-            if (c > 0) asm volatile("s_barrier" ::: "memory");        // everyone finished reading the stage
-            issue_chunk(c, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my pieces of chunk c have landed
-        asm volatile("s_barrier" ::: "memory");                       // ... everyone's, and compute(c-1) is over
-        if constexpr (STAGES == 2) {
-            if (c + 1 < p.cin_chunks) issue_chunk(c + 1, stage ^ 1);  // lands while chunk c computes
-        }
-        const char* s_w = smem + stage * stage_bytes;
-        const char* s_in = s_w + NKS * MI * 1024;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            int off;
-            if constexpr (G % 4 == 0) {          // the 4 k-groups of a k-step share one tap
+      for (int t = 0; t < NT; ++t) {
+        if (c > 0 || t > 0) asm volatile("s_barrier" ::: "memory");       // everyone finished reading the buffers
+        if (!(p.ablate & 2)) {
+            if (t == 0) issue_weights(c);
+            issue_halo(c, t);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // my pieces have landed
+        asm volatile("s_barrier" ::: "memory");                           // ... everyone's
+        // fragment offsets of k-step s (compile-time tap arithmetic when the 4 k-groups of a step share a tap)
+        auto frag_off = [&](int s) -> int {
+            if constexpr (G % 4 == 0) {
                 const int tap = (4 * s) / G, cg0 = (4 * s) % G;
-                off = (tap / KS) * row_pitch + (tap % KS) * PS + (cg0 + g) * 16;
+                return (tap / KS) * row_pitch + (tap % KS) * PS + (cg0 + g) * 16;
             } else {
                 int kg = 4 * s + g;
                 kg = kg < NKG ? kg : NKG - 1;     // padded k-groups: weights are zero, address must stay valid
                 const int tap = kg / G, cg = kg - tap * G;
                 const int dy = tap / KS, dx = tap - dy * KS;
-                off = dy * row_pitch + dx * PS + cg * 16;
+                return dy * row_pitch + dx * PS + cg * 16;
             }
-            frag a[MI], b[NI];
+        };
+        if (p.ablate & 1) continue;
+        // software pipeline over k-steps: fragments of step s+1 are fetched from LDS while step s multiplies
+        frag a[2][MI], b[2][NI];
+        {
+            const int off = frag_off(0);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[mi] = *reinterpret_cast<const frag*>(s_w + ((s * MI + mi) * 64 + lane) * 16);
+            for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const frag*>(s_w + (mi * 64 + lane) * 16);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+            for (int j = 0; j < NI; ++j) b[0][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+        }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < NKS) {
+                const int off = frag_off(s + 1);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    a[nxt][mi] = *reinterpret_cast<const frag*>(s_w + (((s + 1) * MI + mi) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[nxt][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (GE == 8) {
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[j], acc[mi][j], 0, 0, 0);
+                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mi], b[cur][j], acc[t][mi][j], 0, 0, 0);
                     } else {
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][0], b[j][0], acc[mi][j], 0, 0, 0);
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][1], b[j][1], acc[mi][j], 0, 0, 0);
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][2], b[j][2], acc[mi][j], 0, 0, 0);
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][3], b[j][3], acc[mi][j], 0, 0, 0);
+                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][0], b[cur][j][0], acc[t][mi][j], 0, 0, 0);
+                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][1], b[cur][j][1], acc[t][mi][j], 0, 0, 0);
+                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][2], b[cur][j][2], acc[t][mi][j], 0, 0, 0);
+                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][3], b[cur][j][3], acc[t][mi][j], 0, 0, 0);
                     }
                 }
+            if (s + 1 < NKS) __builtin_amdgcn_sched_barrier(0);    // keep the prefetch ahead of the next step's MFMAs
         }
+      }
     }
 
+    // ---- epilogue A (bf16 outputs): + folded-BN shift in the MFMA layout, transpose through LDS (the staging
+    // buffers are free now), then every lane handles 8 consecutive channels of one pixel: residual load and
+    // output store are 16 bytes per lane and contiguous per pixel row (a fragment row is one 16 x Cout*2 B
+    // contiguous span) instead of 8-byte pieces scattered over 16 pixel rows.
+    if constexpr (GE == 8) {
+        if (p.epi_lds && !p.out_f32) {
+            constexpr int CO = MI * 16, PITCH = CO + 4;                   // floats per staged pixel row
+            asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
+            float* stg = reinterpret_cast<float*>(smem) + wave * (NI * 16 * PITCH);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int co = (nb * MI + mi) * 16 + g * 4;
+                        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (nb * MI + mi < p.cout_frags) bs = *reinterpret_cast<const float4*>(p.bias + co);
+                        *reinterpret_cast<float4*>(stg + (j * 16 + ln) * PITCH + mi * 16 + g * 4) =
+                            make_float4(acc[t][mi][j][0] + bs.x, acc[t][mi][j][1] + bs.y, acc[t][mi][j][2] + bs.z, acc[t][mi][j][3] + bs.w);
+                    }
+                // wave-local hand-off: LDS operations of one wave complete in order
+                constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int f = wave * NI + j;
+                    const int fr = f / TWF, fx = f - fr * TWF;
+                    const int oy = oy00 + t * TH + fr;
+#pragma unroll
+                    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+                        const int id = it * 64 + lane;
+                        const int px = id / GROUPS, grp = id - px * GROUPS;
+                        const int ox = ox0 + fx * 16 + px;
+                        const int co = nb * CO + grp * 8;
+                        if (id < ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout) {
+                            const float* sp = stg + (j * 16 + px) * PITCH + grp * 8;
+                            const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+                            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                            const size_t o = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
+                            if (p.res) {
+                                const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) + o);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+                            }
+                            bf16x8 q;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) q[e] = (__bf16)(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o) = q;
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     // epilogue: + folded-BN shift (+ residual) (ReLU) -> store 4 consecutive channels per lane
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int f = wave * NI + j;
         const int fr = f / TWF, fx = f - fr * TWF;
-        const int oy = oy0 + fr, ox = ox0 + fx * 16 + ln;
+        const int oy = oy00 + t * TH + fr, ox = ox0 + fx * 16 + ln;
         if (oy >= p.Hout || ox >= p.Wout) continue;
         const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
@@ -220,8 +295,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvParams p) {
             const int co = cf * 16 + g * 4;
             if (co >= p.cout) continue;                    // padded output channels are never stored
             const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
-            float v0 = acc[mi][j][0] + bs.x, v1 = acc[mi][j][1] + bs.y;
-            float v2 = acc[mi][j][2] + bs.z, v3 = acc[mi][j][3] + bs.w;
+            float v0 = acc[t][mi][j][0] + bs.x, v1 = acc[t][mi][j][1] + bs.y;
+            float v2 = acc[t][mi][j][2] + bs.z, v3 = acc[t][mi][j][3] + bs.w;
             const size_t o = pix * p.out_cstride + p.out_coff + co;
             if (p.res) {
                 if constexpr (GE == 8) {
@@ -252,18 +327,18 @@ typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
-    ConvLaunchFn launch1, launch2;   // single-stage / double-buffered (chunk c+1 DMA under chunk c MFMAs)
+    ConvLaunchFn launch1, launch2;   // NT = 1 / NT = 2 sub-tiles per weight chunk
 };
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int STAGES>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int NT>
 void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, STAGES>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, NT>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

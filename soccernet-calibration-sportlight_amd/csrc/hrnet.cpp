@@ -367,7 +367,9 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         const double m_eff = (double)cout_frags / (nblk * V.mi);
         const double reuse = (double)(V.mi * 4) / (V.mi + 4);           // MFMAs per LDS fragment read (NI=4 nominal)
         const double per_chunk = (double)nks / (nks + 1.0);              // amortisation of the per-chunk sync/load
-        const double score = k_eff * m_eff * (0.55 + 0.45 * reuse / 2.4) * per_chunk;
+        // two workgroups per CU (<= 80 KB of LDS each) hide the staging rounds; judged on a nominal 2-wide tile
+        const double occ = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, 2) <= 80 * 1024 ? 1.0 : 0.55;
+        const double score = k_eff * m_eff * (0.55 + 0.45 * reuse / 2.4) * per_chunk * occ;
         if (score > best + 1e-9) { best = score; L.mi = V.mi; L.g = V.g; }
     }
     L.cout_frags = cout_frags;
@@ -566,49 +568,64 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.Hout = to.H; p.Wout = to.W; p.cout_frags = L.cout_frags; p.cout = L.cout;
     p.out_cstride = to.C; p.out_coff = op.out_coff;
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
-    // pick NI / tile shape / staging depth for this spatial size
+    // pick NI / tile shape / sub-tiles per weight chunk for this spatial size
     const ConvVariant* bestv = nullptr;
-    int best_twf = 1, best_stages = 1; double best_score = -1; size_t best_lds = 0;
+    int best_twf = 1, best_nt = 1; double best_score = -1; size_t best_lds = 0;
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
-    static const int force_st = getenv("SNCAL_FORCE_STAGES") ? atoi(getenv("SNCAL_FORCE_STAGES")) : 0;
+    static const int force_nt = getenv("SNCAL_FORCE_NT") ? atoi(getenv("SNCAL_FORCE_NT")) : 0;
+    bool has_forced = false;
+    for (int v = 0; v < net.nvariants; ++v) {
+        const ConvVariant& V = net.variants[v];
+        if (V.ks == L.k && V.stride == L.stride && V.mi == L.mi && V.g == L.g && V.ni == force_ni) has_forced = true;
+    }
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride || V.mi != L.mi || V.g != L.g) continue;
-        if (force_ni && L.k == 3 && L.stride == 1 && V.ni != force_ni) continue;
+        if (force_ni && has_forced && L.k == 3 && L.stride == 1 && V.ni != force_ni) continue;
         const int F = 4 * V.ni;
+        const size_t wchunk = (size_t)conv_nks(V.ks, V.g) * V.mi * 1024;
         for (int twf = 1; twf <= F; twf *= 2) {
+            if (F % twf) continue;
             const int th = F / twf;
-            const size_t stage = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
-            for (int stages = 1; stages <= 2; ++stages) {
-                if (stages == 2 && L.chunks < 2) continue;
-                if (force_st && stages != force_st && !(force_st == 2 && L.chunks < 2)) continue;
-                const size_t lds = stage * stages;
-                if (lds > 160 * 1024) continue;
-                const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
-                const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
+            const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
+            if (lds > 160 * 1024) continue;
+            for (int nt = 1; nt <= 2; ++nt) {
+                if (force_nt && nt != force_nt && !(force_nt == 2 && V.mi * V.ni > 16)) continue;
+                if (nt == 2 && V.mi * V.ni > 16) continue;                        // 2 accumulator sets must keep 2 waves/SIMD
+                const long ty = (to.H + th * nt - 1) / (th * nt), tx = (to.W + 16 * twf - 1) / (16 * twf);
+                const double eff = (double)to.H * to.W / ((double)ty * th * nt * tx * 16 * twf);
                 const long blocks = ty * tx * sb * L.nblk;
-                const double fill = std::min(1.0, (double)blocks / 256.0);        // at least one workgroup per CU
+                const double fill = std::min(1.0, (double)blocks / 512.0);        // two workgroups per CU
                 const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
                 const int per_cu = (int)std::min<size_t>(2, (160 * 1024) / lds);
-                // overlap of staging with MFMA.  Measured on MI355X (profiles/): a second resident workgroup (2 waves
-                // per SIMD, single stage) beats explicit double buffering at one workgroup per CU by ~1.4x.
-                const double overlap = stages == 1 ? (per_cu >= 2 ? 1.0 : 0.6) : 0.75;
-                const double score = eff * (0.3 + 0.7 * fill) * (0.4 + 0.6 * reuse / 2.4) * overlap;
-                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; best_stages = stages; }
+                // staging/MFMA overlap comes from a second resident workgroup (measured, see conv.hpp)
+                const double overlap = per_cu >= 2 ? 1.0 : 0.55;
+                // the kernels are LDS-fill bound: bytes staged per output pixel fall when the weight chunk is shared
+                const double halo = (double)(lds - wchunk);
+                const double traffic = ((double)wchunk + halo) / ((double)wchunk / nt + halo);
+                (void)traffic;   // measured: sharing the weight chunk (NT=2) does not pay -- rounds are latency-bound
+                const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap * (nt == 2 ? 0.9 : 1.0);
+                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; best_nt = nt; }
             }
         }
     }
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
-    const int th = 4 * bestv->ni / best_twf;
+    const int th = 4 * bestv->ni / best_twf * best_nt;
     p.twf = best_twf;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;
+    {   // LDS-transposed epilogue when the fp32 tile of the 4 waves fits in the staging buffers and Cout is whole 8-groups
+        static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
+        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;
+        p.epi_lds = (epi && net.dtype == SNCAL_BF16 && !op.out_f32 && need <= best_lds && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0) ? 1 : 0;
+    }
+    { static const int abl = getenv("SNCAL_ABLATE") ? atoi(getenv("SNCAL_ABLATE")) : 0; p.ablate = abl; }
     p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
-    (best_stages == 2 ? bestv->launch2 : bestv->launch1)(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    (best_nt == 2 ? bestv->launch2 : bestv->launch1)(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,ST%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
-                              bestv->ni, L.mi, L.g, best_stages);
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,NT%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+                              bestv->ni, L.mi, L.g, best_nt);
         const double px = (double)sb * to.H * to.W;
         net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
         net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +

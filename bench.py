@@ -123,20 +123,22 @@ def main():
                                  algorithm='iterative_voter', lines_file=None, max_rmse=55.0, max_rmse_rel=5.0,
                                  min_points=5, min_focal_length=10.0, min_points_per_plane=6,
                                  min_points_for_refinement=6, reliable_thresh=57)
-    rec_bytes = ctypes.sizeof(sncal_amd._lib.Camera)
-    rec_net = torch.empty((B, rec_bytes), dtype=torch.uint8, device=dev)
-    rec_syn = torch.empty((B, rec_bytes), dtype=torch.uint8, device=dev)
+    pipe = sncal_amd.CalibrationPipeline(net, cc, decode_size=(540, 960))
+    last = {}
     from sncal_amd.dist import pack_records, gather_records
 
     def step():
-        _, kpts = net.forward(x, want_heat=False, decode_size=(540, 960))
-        cc.solve_device(kpts, out=rec_net)
-        cc.solve_device(kp_synth, out=rec_syn)
+        # forward + decode on the main stream; both solves on the pipeline's side stream (they overlap the next
+        # step's convolutions); every solve is complete before the closing fence of the timed region
+        kpts, rec_net, rec_syn = pipe.submit(x, extra_keypoints=kp_synth)
+        last['rec_syn'] = rec_syn
         if world > 1:   # the single collective of the path: per-frame records to every rank (RCCL over xGMI)
+            pipe.join()
             gather_records(pack_records(kpts, rec_net, rec_syn))
         return kpts
 
     def fence():
+        pipe.join()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -156,6 +158,7 @@ def main():
     net.set_profiling(False)
     # solve-stage time, measured separately after the timed region (torch events see torch's current stream,
     # which is the stream libsncal launches on)
+    rec_syn = last['rec_syn']
     ev[0].record()
     for _ in range(3):
         cc.solve_device(kp_synth, out=rec_syn)

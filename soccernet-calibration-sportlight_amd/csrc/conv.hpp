@@ -139,6 +139,36 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int n_halo_instr = halo_bytes / 1024;
 
+    // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
+    // known up front, so the residual is requested now and arrives under the main loop
+    constexpr int EPI_CO = MI * 16, EPI_GROUPS = EPI_CO / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;
+    bf16x8 res_pf[NT][NI][EPI_ITERS];
+    const bool epi_a = GE == 8 && p.epi_lds && !p.out_f32;
+    if constexpr (GE == 8) {
+        if (epi_a && p.res) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int f = wave * NI + j;
+                    const int fr = f / TWF, fx = f - fr * TWF;
+                    const int oy = oy00 + t * TH + fr;
+#pragma unroll
+                    for (int it = 0; it < EPI_ITERS; ++it) {
+                        const int id = it * 64 + lane;
+                        const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
+                        const int ox = ox0 + fx * 16 + px;
+                        const int co = nb * EPI_CO + grp * 8;
+                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (id < EPI_ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout)
+                            r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) +
+                                (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co);
+                        res_pf[t][j][it] = r;
+                    }
+                }
+        }
+    }
+
     char* const s_w = smem;
     char* const s_in = smem + NKS * MI * 1024;
     auto issue_weights = [&](int c) {        // lane-linear 1 KB pieces, round-robin over the 4 waves
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     // output store are 16 bytes per lane and contiguous per pixel row (a fragment row is one 16 x Cout*2 B
     // contiguous span) instead of 8-byte pieces scattered over 16 pixel rows.
     if constexpr (GE == 8) {
-        if (p.epi_lds && !p.out_f32) {
+        if (epi_a) {
             constexpr int CO = MI * 16, PITCH = CO + 4;                   // floats per staged pixel row
             asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
             float* stg = reinterpret_cast<float*>(smem) + wave * (NI * 16 * PITCH);
@@ -263,9 +293,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
                             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                             const size_t o = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
                             if (p.res) {
-                                const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) + o);
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+                                for (int e = 0; e < 8; ++e) v[e] += (float)res_pf[t][j][it][e];
                             }
                             bf16x8 q;
 #pragma unroll

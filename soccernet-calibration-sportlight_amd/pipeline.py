@@ -1,0 +1,56 @@
+"""Frame pipeline: the production loop of /root/reference/src/utils/make_submit.py:42-75 on one GPU.
+
+make_submit pushes each prediction row to a 16-process CPU pool; here the network runs on the caller's
+stream and the batched camera solve runs on a side stream, ordered by events, so the solve of batch i
+overlaps the convolutions of batch i+1 (the solve is latency-bound and only occupies 64 wavefronts).
+"""
+import torch
+
+from . import _lib
+
+
+class CalibrationPipeline:
+    def __init__(self, net, calibrator, decode_size=(540, 960)):
+        self.net = net
+        self.calibrator = calibrator
+        self.decode_size = decode_size
+        self.device = net.device
+        self.solve_stream = torch.cuda.Stream(device=self.device)
+        self._pending = []
+
+    def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None):
+        """frames (B,3,H,W) fp32 on the GPU.  Enqueues forward+decode on the current stream and the solve(s)
+        on the side stream; returns (kpts, records[, extra_records]) device tensors (asynchronous)."""
+        main = torch.cuda.current_stream(self.device)
+        _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        lp = self.calibrator.line_points_array(names)
+        d_lp = torch.from_numpy(lp).to(self.device, non_blocking=True) if lp is not None else None
+        with torch.cuda.stream(self.solve_stream):
+            self.solve_stream.wait_event(ready)
+            kpts.record_stream(self.solve_stream)
+            rec = self.calibrator.solve_device(kpts, d_lp)
+            out = [kpts, rec]
+            if extra_keypoints is not None:
+                out.append(self.calibrator.solve_device(extra_keypoints))
+        done = torch.cuda.Event()
+        done.record(self.solve_stream)
+        self._pending.append(done)
+        if len(self._pending) > 4:          # bound the number of batches in flight
+            self._pending.pop(0).synchronize()
+        return tuple(out)
+
+    def join(self):
+        """Make the current stream wait for every enqueued solve."""
+        main = torch.cuda.current_stream(self.device)
+        for ev in self._pending:
+            main.wait_event(ev)
+        self._pending.clear()
+
+    def cameras(self, records: torch.Tensor):
+        """records from submit() -> list of Optional[Camera] (synchronises)."""
+        from .prediction import camera_from_record
+        self.join()
+        torch.cuda.current_stream(self.device).synchronize()
+        return [camera_from_record(r, self.calibrator.img_size) for r in self.calibrator.records(records)]

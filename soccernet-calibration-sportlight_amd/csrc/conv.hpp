@@ -30,10 +30,10 @@
 // fall on the pitch padding, outside the image or beyond Cin fetch out of bounds and the buffer descriptor
 // returns zeros -- zero padding costs nothing.  Barriers are raw s_barrier + explicit s_waitcnt vmcnt so
 // that hipcc does not drain the DMA queue early.  Measured on MI355X the kernel is bound by the LDS-fill
-// rate (L2 -> LDS, ~5.7 TB/s chip-wide) and most of the fill is the weight chunk that every workgroup
-// re-reads, so a workgroup can walk NT vertically stacked sub-tiles per weight chunk (NT accumulator sets,
-// one halo buffer): the weight bytes per output pixel drop by NT.  Staging/MFMA overlap comes from a
-// second resident workgroup per CU (explicit double buffering at one workgroup per CU measured 1.4x slower).
+// staging ROUNDS (DMA issue + memory latency + barrier, ~2.5 us each, independent of the bytes moved: sharing a
+// weight chunk between two sub-tiles did not pay).  Two ways to hide a round are instantiated: ST == 1 relies
+// on a second resident workgroup per CU (LDS <= 80 KB), ST == 2 double-buffers the chunk inside the workgroup
+// (the next chunk's DMA is issued right after the per-chunk barrier and lands under the current MFMAs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -64,6 +64,7 @@ struct ConvParams {
     int relu, out_f32;
     unsigned w_bytes;                // size of the packed weight buffer (buffer descriptor range)
     int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA (results invalid)
+    int skew;                        // tuning aid: initial delay (x64 clk) of every second co-resident workgroup
     int epi_lds;                     // 1: transpose the output tile through LDS for 16-byte coalesced stores
 };
 
@@ -71,6 +72,7 @@ struct ConvParams {
 // (found by enumerating the ds_read_b128 lane groups of MI355X_MICROARCH.md "LDS")
 __host__ __device__ constexpr int halo_pitch(int G, int stride) {
     int slots = G;
+    if (G == 3) return 48;            // 24-channel chunks trade a 2-way read conflict for LDS space (3 workgroups/CU)
     if (stride == 1) { if (G > 1) while (slots % 4 != 2) ++slots; }
     else { if (G > 1 && slots % 2 == 0) ++slots; }
     return slots * 16;
@@ -88,7 +90,7 @@ inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int NT>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int ST>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int nb = blockIdx.y;
     const int TWF = p.twf, TH = 4 * NI / TWF;
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
-    const int oy00 = ty * TH * NT, ox0 = tx * 16 * TWF;       // NT sub-tiles stacked in y
+    constexpr int NT = 1;
+    const int oy00 = ty * TH, ox0 = tx * 16 * TWF;
     const int ix0 = ox0 * STRIDE - PAD;
     const int g = lane >> 4, ln = lane & 15;
     const int npix = HALO_H * HALO_W;
@@ -169,15 +172,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         }
     }
 
-    char* const s_w = smem;
-    char* const s_in = smem + NKS * MI * 1024;
-    auto issue_weights = [&](int c) {        // lane-linear 1 KB pieces, round-robin over the 4 waves
+    auto issue_chunk = [&](int c, int stage) {
+        char* const sw = smem + stage * stage_bytes;
+        char* const si = sw + NKS * MI * 1024;
+        // weights: lane-linear 1 KB pieces, round-robin over the 4 waves
         const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * (NKS * MI * 1024));
         for (int i = wave; i < NKS * MI; i += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(s_w + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
-    };
-    auto issue_halo = [&](int c, int t) {    // slot s of the [pixel][SLOTS] image; padding slots / outside-image
-        const int iy0 = (oy00 + t * TH) * STRIDE - PAD;   // pixels read out of range and come back as zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(sw + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
+        // halo: slot s of the [pixel][SLOTS] image; padding slots / outside-image pixels read out of range -> zeros
+        const int iy0 = oy00 * STRIDE - PAD;
         const unsigned cbase = (unsigned)(c * G * 16);
         for (int j = wave; j < n_halo_instr; j += 4) {
             const int slot = j * 64 + lane;
@@ -187,20 +190,29 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
                             (c * G + cg) * GE < p.Cin;
             const unsigned voff = ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(s_in + j * 1024), 16, voff, cbase, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(si + j * 1024), 16, voff, cbase, 0, 0);
         }
     };
 
+    if (p.skew > 0 && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {      // de-phase the two workgroups of a CU
+        for (int k = 0; k < p.skew; ++k) __builtin_amdgcn_s_sleep(16);
+    }
+    if (ST == 2 && !(p.ablate & 2)) issue_chunk(0, 0);
     for (int c = 0; c < p.cin_chunks; ++c) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (c > 0 || t > 0) asm volatile("s_barrier" ::: "memory");       // everyone finished reading the buffers
-        if (!(p.ablate & 2)) {
-            if (t == 0) issue_weights(c);
-            issue_halo(c, t);
+      constexpr int t = 0;
+      {
+        const int stage = ST == 2 ? (c & 1) : 0;
+        if constexpr (ST == 1) {
+            if (c > 0) asm volatile("s_barrier" ::: "memory");           // everyone finished reading the buffers
+            if (!(p.ablate & 2)) issue_chunk(c, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // my pieces have landed
-        asm volatile("s_barrier" ::: "memory");                           // ... everyone's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // my pieces of chunk c have landed
+        asm volatile("s_barrier" ::: "memory");                           // ... everyone's; compute(c-1) is over
+        if constexpr (ST == 2) {
+            if (c + 1 < p.cin_chunks && !(p.ablate & 2)) issue_chunk(c + 1, stage ^ 1);   // lands under chunk c's MFMAs
+        }
+        const char* const s_w = smem + stage * stage_bytes;
+        const char* const s_in = s_w + NKS * MI * 1024;
         // fragment offsets of k-step s (compile-time tap arithmetic when the 4 k-groups of a step share a tap)
         auto frag_off = [&](int s) -> int {
             if constexpr (G % 4 == 0) {
@@ -356,18 +368,18 @@ typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
-    ConvLaunchFn launch1, launch2;   // NT = 1 / NT = 2 sub-tiles per weight chunk
+    ConvLaunchFn launch1, launch2;   // ST = 1 (single stage) / ST = 2 (double-buffered chunks)
 };
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int NT>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int ST>
 void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, ST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, NT>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, ST>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

@@ -360,6 +360,8 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride) continue;
         if (force_mi && L.k == 3 && L.stride == 1 && V.mi != force_mi && cout_frags % force_mi == 0) continue;
+        { static const int force_g = getenv("SNCAL_FORCE_G") ? atoi(getenv("SNCAL_FORCE_G")) : 0;
+          if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue; }
         const int chunks = (L.cin_phys + V.g * ge - 1) / (V.g * ge);
         const int nks = conv_nks(V.ks, V.g);
         const double k_eff = (double)(L.k * L.k * L.cin_phys / ge) / (double)(chunks * nks * 4);
@@ -572,7 +574,10 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     const ConvVariant* bestv = nullptr;
     int best_twf = 1, best_nt = 1; double best_score = -1; size_t best_lds = 0;
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
-    static const int force_nt = getenv("SNCAL_FORCE_NT") ? atoi(getenv("SNCAL_FORCE_NT")) : 0;
+    static const int force_nt = getenv("SNCAL_FORCE_ST") ? atoi(getenv("SNCAL_FORCE_ST")) : 0;
+    static const double st2_two = getenv("SNCAL_ST2_TWO") ? atof(getenv("SNCAL_ST2_TWO")) : 1.05;
+    static const double three_cu = getenv("SNCAL_THREE_CU") ? atof(getenv("SNCAL_THREE_CU")) : 1.0;
+    static const double st2_one = getenv("SNCAL_ST2_ONE") ? atof(getenv("SNCAL_ST2_ONE")) : 0.8;
     bool has_forced = false;
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
@@ -589,42 +594,43 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
             const int th = F / twf;
             const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
             if (lds > 160 * 1024) continue;
-            for (int nt = 1; nt <= 2; ++nt) {
-                if (force_nt && nt != force_nt && !(force_nt == 2 && V.mi * V.ni > 16)) continue;
-                if (nt == 2 && V.mi * V.ni > 16) continue;                        // 2 accumulator sets must keep 2 waves/SIMD
-                const long ty = (to.H + th * nt - 1) / (th * nt), tx = (to.W + 16 * twf - 1) / (16 * twf);
-                const double eff = (double)to.H * to.W / ((double)ty * th * nt * tx * 16 * twf);
+            for (int nt = 1; nt <= 2; ++nt) {                                     // nt = staging depth ST
+                if (force_nt && nt != force_nt && !(force_nt == 2 && L.chunks < 2)) continue;
+                if (nt == 2 && L.chunks < 2) continue;
+                const size_t lds_t = lds * nt;
+                if (lds_t > 160 * 1024) continue;
+                const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
+                const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
                 const long blocks = ty * tx * sb * L.nblk;
-                const double fill = std::min(1.0, (double)blocks / 512.0);        // two workgroups per CU
+                const int per_cu = (int)std::min<size_t>(3, (160 * 1024) / lds_t);
+                const double fill = std::min(1.0, (double)blocks / (256.0 * per_cu));
                 const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
-                const int per_cu = (int)std::min<size_t>(2, (160 * 1024) / lds);
-                // staging/MFMA overlap comes from a second resident workgroup (measured, see conv.hpp)
-                const double overlap = per_cu >= 2 ? 1.0 : 0.55;
-                // the kernels are LDS-fill bound: bytes staged per output pixel fall when the weight chunk is shared
-                const double halo = (double)(lds - wchunk);
-                const double traffic = ((double)wchunk + halo) / ((double)wchunk / nt + halo);
-                (void)traffic;   // measured: sharing the weight chunk (NT=2) does not pay -- rounds are latency-bound
-                const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap * (nt == 2 ? 0.9 : 1.0);
-                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; best_nt = nt; }
+                // a staging round (DMA issue + latency + barrier) is hidden by a second resident workgroup (ST1)
+                // or by the workgroup's own second stage (ST2); calibrated on MI355X, see profiles/
+                const double overlap = nt == 1 ? (per_cu >= 3 ? three_cu : per_cu >= 2 ? 1.0 : 0.55) : (per_cu >= 2 ? st2_two : st2_one);
+                const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap;
+                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds_t; best_nt = nt; }
             }
         }
     }
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
-    const int th = 4 * bestv->ni / best_twf * best_nt;
+    const int th = 4 * bestv->ni / best_twf;
     p.twf = best_twf;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;
     {   // LDS-transposed epilogue when the fp32 tile of the 4 waves fits in the staging buffers and Cout is whole 8-groups
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
-        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;
+        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;   // fp32 tile of the 4 waves
         p.epi_lds = (epi && net.dtype == SNCAL_BF16 && !op.out_f32 && need <= best_lds && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0) ? 1 : 0;
     }
+    { static const int sk = getenv("SNCAL_SKEW") ? atoi(getenv("SNCAL_SKEW")) : 0; p.skew = sk; }
     { static const int abl = getenv("SNCAL_ABLATE") ? atoi(getenv("SNCAL_ABLATE")) : 0; p.ablate = abl; }
     p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
+    { static const int extra = getenv("SNCAL_EXTRA_LDS") ? atoi(getenv("SNCAL_EXTRA_LDS")) : 0; best_lds = std::min<size_t>(best_lds + extra, 160 * 1024); }
     (best_nt == 2 ? bestv->launch2 : bestv->launch1)(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,NT%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,ST%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
                               bestv->ni, L.mi, L.g, best_nt);
         const double px = (double)sb * to.H * to.W;
         net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;

@@ -1,0 +1,100 @@
+"""GPU: the other BASELINE.json configurations as parity cases (C2 W32 480x270 batch 32 decode-only; C4 keypoint +
+line networks joined through the line-intersection candidates; C5 1920x1080 shapes), plus the frame pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode as od
+from oracle import hrnet_ref as hr
+from oracle import lines as ol
+from oracle import solve as osolve
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_w32_480x270_batch32_decode(sncal, cuda):
+    """C2: HRNet-W32 (build-defined widths 32/64/128/256; the reference ships no w32 yaml) at 480x270, batch 32,
+    heatmap argmax only.  Head is 136x240 while the stem is 135x240 -> stem interpolation path, unfused head."""
+    cfg = hr.load_config('hrnet_w32')
+    sd = hr.seeded_state_dict(cfg, 11, 2.0)
+    x = hr.seeded_input(32, 270, 480, 12)
+    net = sncal.HRNetHeatmap('hrnet_w32', dtype='fp32', device=cuda)
+    net.load_state_dict(sd)
+    heat, kp = net.forward(x.to(cuda), want_heat=True, decode_size=(540, 960))
+    assert heat.shape == (32, 58, 136, 240) and kp.shape == (32, 57, 3)
+    ref = hr.forward(sd, x[:2], cfg).numpy()                     # the oracle on 2 of the 32 frames (seconds on CPU)
+    assert np.abs(heat[:2].cpu().numpy() - ref).max() <= 2e-4
+    assert np.array_equal(kp[:2].cpu().numpy()[..., :2], od.keypoint_decode(ref, (540, 960))[..., :2])
+    # size-independent property over the whole batch: the fused decode equals the oracle decode of our own heatmaps
+    assert np.array_equal(kp.cpu().numpy(), od.keypoint_decode(heat.cpu().numpy(), (540, 960)))
+    # bf16 engine on the same batch stays close
+    netb = sncal.HRNetHeatmap('hrnet_w32', dtype='bf16', device=cuda)
+    netb.load_state_dict(sd)
+    hb, _ = netb.forward(x.to(cuda))
+    assert (hb[:2].cpu().numpy() - ref).__abs__().max() < 0.5
+
+
+def test_c4_keypoint_and_line_networks_joined(sncal, cuda):
+    """C4 data flow on small nets: line net -> 2-peak decode -> slope/intercept -> intersections -> extra keypoint
+    candidates for the solve (export_line_result.py:85-131 + prediction.py:105-124), all through the host mirror."""
+    cfgl = hr.load_config('line_hrnet_w18')
+    sdl = hr.seeded_state_dict(cfgl, 4, 4.0)
+    x = hr.seeded_input(1, 64, 96, 5)
+    lnet = sncal.HRNetHeatmap('line_hrnet_w18', dtype='fp32', device=cuda)
+    lnet.load_state_dict(sdl)
+    heat = lnet(x.to(cuda))[-1]
+    dec = sncal.EHMPredictionTransform.mask_heat_points_gauss(heat, sigma=3)
+    ref_heat = hr.forward(sdl, x, cfgl).numpy()
+    ref_dec = od.line_decode(ref_heat, 3.0, 1.0)
+    assert np.array_equal(dec.cpu().numpy()[..., :2], ref_dec[..., :2])
+    lines_m, pts_m = sncal.lines.get_line_data(dec, scale=4, prob_thre=0.0)
+    lines_o, _ = ol.get_line_data(ref_dec, scale=4, prob_thre=0.0)
+    assert lines_m.keys() == lines_o.keys() and len(lines_m) > 0
+    km = sncal.lines.lines_to_keypoints({k: v for k, v in lines_m.items() if v[0] is not None})
+    ko = ol.lines_to_keypoints({k: v for k, v in lines_o.items() if v[0] is not None})
+    assert km.keys() == ko.keys()
+    for k in km:
+        assert np.allclose(km[k], ko[k], rtol=1e-4, atol=1e-3)
+    arr = sncal.lines.keypoints_to_array(km)
+    assert arr.shape == (30, 3) and arr[:, 2].sum() == len(km)
+
+
+def test_c5_1080p_shapes(sncal, cuda):
+    """C5 geometry: 1920x1080 input -> (B,58,540,960) heatmaps, decode grid step 1 px (transforms.py:234-235).
+    Small net, fp32, checked against the oracle on one frame (the fp8 arithmetic of C5 is not built yet)."""
+    cfg = hr.load_config('hrnet_w18')
+    sd = hr.seeded_state_dict(cfg, 31, 4.0)
+    x = hr.seeded_input(1, 1080, 1920, 32)
+    net = sncal.HRNetHeatmap('hrnet_w18', dtype='fp32', device=cuda)
+    net.load_state_dict(sd)
+    heat, kp = net.forward(x.to(cuda), want_heat=True, decode_size=(540, 960))
+    assert heat.shape == (1, 58, 540, 960)
+    ref = hr.forward(sd, x, cfg).numpy()
+    assert np.abs(heat.cpu().numpy() - ref).max() <= 2e-4
+    assert np.array_equal(kp.cpu().numpy()[..., :2], od.keypoint_decode(ref, (540, 960))[..., :2])
+
+
+def test_pipeline_overlapped_solve_matches_direct(sncal, cuda):
+    """CalibrationPipeline (side-stream solve) returns the same cameras as the synchronous calls."""
+    cfg = hr.load_config('hrnet_w18')
+    net = sncal.HRNetHeatmap('hrnet_w18', dtype='bf16', device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 9, 4.0))
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter',
+                             max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0,
+                             min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
+    pipe = sncal.CalibrationPipeline(net, cc)
+    x = hr.seeded_input(4, 135, 240, 10).to(cuda)
+    kps = torch.from_numpy(np.stack([synth.synth_keypoints(s)[0] for s in range(700, 708)])).to(cuda)
+    outs = [pipe.submit(x, extra_keypoints=kps) for _ in range(3)]
+    cams = pipe.cameras(outs[-1][2])
+    direct = cc.solve_batch(kps)
+    for a, b in zip(cams, direct):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.rmse == b.rmse and np.array_equal(a.rotation, b.rotation)
+    _, k_direct = net.forward(x, want_heat=False, decode_size=(540, 960))
+    assert torch.equal(outs[0][0], k_direct)
+    oc = osolve.CameraCreatorOracle()
+    o0 = oc(kps[0].cpu().numpy(), None)
+    assert (o0 is None) == (cams[0] is None)

@@ -23,6 +23,7 @@
 // repack -- no LDS round trip, no shuffles.  One barrier per 32-channel slice orders the source-box DMA.
 #include "common.hpp"
 #include "head.hpp"
+#include <cstdlib>
 
 #pragma clang fp contract(fast)
 
@@ -39,7 +40,8 @@ constexpr int HEAD_MAX_DMA = 4;            // DMA instructions per wave per slic
 template <int M2, int NSRC>
 __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
     constexpr int KS1 = 2;
-    constexpr int HEAD_BUF = NSRC * HEAD_SRC_LDS;
+    constexpr int OFF_W0 = NSRC * HEAD_SRC_LDS, OFF_W1 = OFF_W0 + 2 * KS1 * 1024, OFF_B0 = OFF_W1 + M2 * 1024;
+    constexpr int HEAD_BUF = OFF_B0 + 1024;     // per q-slice: source boxes, stage-1 / stage-2 A fragments, BN shift
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * HEAD_BUF bytes
     const int lane = threadIdx.x & 63, g = lane >> 4, ln = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,7 +83,13 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
             }
         }
     }
+    // everything the slice loop consumes comes through LDS-DMA: an ordinary global load inside the loop would
+    // make hipcc wait vmcnt(0) at its first use and drain the prefetch every iteration
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w0), 0, p.NQ * 2 * KS1 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, p.NQ * M2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias0), 0, p.HP * 4, 0x00020000);
     auto issue_slice = [&](int q, int buf) {
+        char* const base = smem + buf * HEAD_BUF;
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_DMA; ++k) {
 #pragma unroll
@@ -91,10 +99,19 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
                     const size_t img = (size_t)p.Hs[s] * p.Ws[s] * p.HP * 2;
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<char*>(reinterpret_cast<const char*>(p.src[s])) + (size_t)n * img, 0, (int)img, 0x00020000);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + buf * HEAD_BUF + dma_lds[k]), 16,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + dma_lds[k]), 16,
                                                              dma_voff[k], (unsigned)(q * 64), 0, 0);
                 }
         }
+        // A fragments of the slice: wave w brings stage-1 piece w (4 pieces) and stage-2 piece w (M2 pieces)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0, (lds_void*)(base + OFF_W0 + wave * 1024), 16, (unsigned)(lane * 16),
+                                                 (unsigned)((q * 2 * KS1 + wave) * 1024), 0, 0);
+        if (wave < M2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_void*)(base + OFF_W1 + wave * 1024), 16, (unsigned)(lane * 16),
+                                                     (unsigned)((q * M2 + wave) * 1024), 0, 0);
+        if (wave == 3)      // 32 shift values = 128 B; the other lanes read out of range
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b0, (lds_void*)(base + OFF_B0), 16,
+                                                     lane < 8 ? (unsigned)(lane * 16) : 0x80000000u, (unsigned)(q * 128), 0, 0);
     };
     issue_slice(0, 0);
 
@@ -130,27 +147,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
 #pragma unroll
     for (int mi = 0; mi < M2; ++mi) acc2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const uint4* w0 = reinterpret_cast<const uint4*>(p.w0);
-    const uint4* w1 = reinterpret_cast<const uint4*>(p.w1);
     for (int q = 0; q < p.NQ; ++q) {
         const int buf = q & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of slice q landed
         asm volatile("s_barrier" ::: "memory");              // everyone's did; everyone is done with slice q-1
         if (q + 1 < p.NQ) issue_slice(q + 1, buf ^ 1);       // lands while slice q is consumed
+        const char* const sb = smem + buf * HEAD_BUF;
         // ---- stage 1: 32 hidden channels x 16 pixels, K = direct channels ------------------------------
         f32x4 acc1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const uint4 raw = w0[((q * 2 + f) * KS1 + ks) * 64 + lane];
-                acc1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, raw), bD[ks], acc1[f], 0, 0, 0);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + OFF_W0 + ((f * KS1 + ks) * 64 + lane) * 16);
+                acc1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bD[ks], acc1[f], 0, 0, 0);
             }
         // ---- gather (from LDS) + folded BN shift + ReLU: lane owns channels q*32 + g*8 .. +7 of its pixel ----
-        const int c0 = q * 32 + g * 8;
-        const float4 bs0 = *reinterpret_cast<const float4*>(p.bias0 + c0);
-        const float4 bs1 = *reinterpret_cast<const float4*>(p.bias0 + c0 + 4);
-        const char* sb = smem + buf * HEAD_BUF;
+        const float4 bs0 = *reinterpret_cast<const float4*>(sb + OFF_B0 + g * 32);
+        const float4 bs1 = *reinterpret_cast<const float4*>(sb + OFF_B0 + g * 32 + 16);
         float v[8] = {acc1[0][0] + bs0.x, acc1[0][1] + bs0.y, acc1[0][2] + bs0.z, acc1[0][3] + bs0.w,
                       acc1[1][0] + bs1.x, acc1[1][1] + bs1.y, acc1[1][2] + bs1.z, acc1[1][3] + bs1.w};
 #pragma unroll
@@ -170,8 +184,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
         // ---- stage 2: logits += W1[:, q-slice] . h -------------------------------------------------------
 #pragma unroll
         for (int mi = 0; mi < M2; ++mi) {
-            const uint4 raw = w1[(q * M2 + mi) * 64 + lane];
-            acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, raw), bH, acc2[mi], 0, 0, 0);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + OFF_W1 + (mi * 64 + lane) * 16);
+            acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bH, acc2[mi], 0, 0, 0);
         }
     }
     // ---- logits (+ conv bias) -> fp32 NHWC [P][LC]; lane holds classes mi*16 + g*4 .. +3 of its pixel -------
@@ -189,9 +203,9 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
 template <int M2>
 void launch_nsrc(const HeadParams& q, unsigned blocks, hipStream_t s) {
     switch (q.nsrc) {
-        case 3: hipLaunchKernelGGL((head_fused_kernel<M2, 3>), dim3(blocks), dim3(256), (size_t)2 * q.nsrc * HEAD_SRC_LDS, s, q); break;
-        case 4: hipLaunchKernelGGL((head_fused_kernel<M2, 4>), dim3(blocks), dim3(256), (size_t)2 * q.nsrc * HEAD_SRC_LDS, s, q); break;
-        default: hipLaunchKernelGGL((head_fused_kernel<M2, 5>), dim3(blocks), dim3(256), (size_t)2 * q.nsrc * HEAD_SRC_LDS, s, q); break;
+        case 3: hipLaunchKernelGGL((head_fused_kernel<M2, 3>), dim3(blocks), dim3(256), (size_t)2 * (q.nsrc * HEAD_SRC_LDS + (4 + M2 + 1) * 1024), s, q); break;
+        case 4: hipLaunchKernelGGL((head_fused_kernel<M2, 4>), dim3(blocks), dim3(256), (size_t)2 * (q.nsrc * HEAD_SRC_LDS + (4 + M2 + 1) * 1024), s, q); break;
+        default: hipLaunchKernelGGL((head_fused_kernel<M2, 5>), dim3(blocks), dim3(256), (size_t)2 * (q.nsrc * HEAD_SRC_LDS + (4 + M2 + 1) * 1024), s, q); break;
     }
 }
 

@@ -177,6 +177,12 @@ def main():
         total_ms = sum(p['ms'] for p in prof)
         dom = max(convs, key=lambda p: p['ms'])
         ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/r01_pmc_hbm_traffic.md)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                traffic = json.load(f).get(dom['kernel'])
+        except OSError:
+            pass
         peak = PEAK_TFLOPS[args.dtype]
         out = {
             'metric': 'frames/sec (HRNet-W48 960x540 + PnP)', 'value': round(world * B * args.steps / dt, 2),
@@ -190,7 +196,7 @@ def main():
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * FLOP_PER_FRAME / 1e12, 1),
                        'kernel_time_share': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(prof, key=lambda q: -q['ms'])[:8]}},
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(ach / peak, 4), 'traffic': None, 'launches': dom['launches'],
+                         'frac': round(ach / peak, 4), 'traffic': traffic, 'launches': dom['launches'],
                          'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                          'flops_per_launch': round(dom['flops'] / dom['launches'], 0),
                          'share_of_gpu_time': round(dom['ms'] / total_ms, 4)},

@@ -12,7 +12,7 @@
 //     DECODE  D1 keypoint decode (decode.hip)
 // Tensors get offsets inside one caller-provided workspace from a lifetime-based first-fit allocator, so a
 // forward is a fixed sequence of kernel launches with no allocation.  Frames are processed in sub-batches
-// (SNCAL_SUBBATCH, default 32) so that the activations of a sub-batch stay Infinity-Cache sized.
+// (SNCAL_SUBBATCH, default 64) so that the activations of a sub-batch stay Infinity-Cache sized.
 #include "common.hpp"
 #include "conv.hpp"
 #include "ops.hpp"
@@ -95,7 +95,7 @@ struct sncal_hrnet {
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
     int cur_group = GRP_ALL;
     bool finalized = false;
-    int subbatch = 32;
+    int subbatch = 64;
     const ConvVariant* variants = nullptr;
     int nvariants = 0;
     // cached per-(sb,H,W) layout

@@ -618,10 +618,14 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.twf = best_twf;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;
-    {   // LDS-transposed epilogue when the fp32 tile of the 4 waves fits in the staging buffers and Cout is whole 8-groups
+    {   // LDS-transposed epilogue: the fp32 tile of the 4 waves is staged in the (grown, if that keeps two
+        // workgroups per CU) dynamic LDS; needs whole 8-channel groups
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
-        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;   // fp32 tile of the 4 waves
-        p.epi_lds = (epi && net.dtype == SNCAL_BF16 && !op.out_f32 && need <= best_lds && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0) ? 1 : 0;
+        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;
+        const bool shape_ok = net.dtype == SNCAL_BF16 && !op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0;
+        const bool fits = need <= best_lds || (need <= 80 * 1024 && best_lds <= 80 * 1024) || need <= 52 * 1024;
+        p.epi_lds = (epi && shape_ok && fits) ? 1 : 0;
+        if (p.epi_lds && need > best_lds) best_lds = need;
     }
     { static const int sk = getenv("SNCAL_SKEW") ? atoi(getenv("SNCAL_SKEW")) : 0; p.skew = sk; }
     { static const int abl = getenv("SNCAL_ABLATE") ? atoi(getenv("SNCAL_ABLATE")) : 0; p.ablate = abl; }

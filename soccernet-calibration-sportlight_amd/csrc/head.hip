@@ -31,6 +31,7 @@ namespace sncal {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr int HEAD_TH = 4;                 // tile = 4 rows x 16 columns of head pixels; one wave owns one row
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
     const int yc = min(y, p.H - 1), xc = min(x, p.W - 1);
     const long pix = ((long)n * p.H + yc) * p.W + xc;
     unsigned lo00[NSRC], ldx[NSRC], ldy[NSRC];     // LDS byte offsets of the taps
-    float w00[NSRC], w01[NSRC], w10[NSRC], w11[NSRC];
+    bf16x2 wtop[NSRC], wbot[NSRC];     // (w00, w01) and (w10, w11) as bf16 pairs for v_dot2c_f32_bf16
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
         const float fy = p.sy[s] * (float)yc, fx = p.sx[s] * (float)xc;   // PyTorch align_corners=True index
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
         iy = iy > p.Hs[s] - 1 ? p.Hs[s] - 1 : iy;
         ix = ix > p.Ws[s] - 1 ? p.Ws[s] - 1 : ix;
         const float ly1 = fy - (float)iy, lx1 = fx - (float)ix;
-        w00[s] = (1.f - lx1) * (1.f - ly1); w01[s] = lx1 * (1.f - ly1); w10[s] = (1.f - lx1) * ly1; w11[s] = lx1 * ly1;
+        wtop[s][0] = (__bf16)((1.f - lx1) * (1.f - ly1)); wtop[s][1] = (__bf16)(lx1 * (1.f - ly1));
+        wbot[s][0] = (__bf16)((1.f - lx1) * ly1); wbot[s][1] = (__bf16)(lx1 * ly1);
         lo00[s] = (unsigned)(s * HEAD_SRC_LDS + ((iy - by0[s]) * bw[s] + (ix - bx0[s])) * 64 + g * 16);
         ldx[s] = ix < p.Ws[s] - 1 ? 64u : 0u;
         ldy[s] = iy < p.Hs[s] - 1 ? (unsigned)(bw[s] * 64) : 0u;
@@ -170,13 +172,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadParams p) {
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) {
             const char* t = sb + lo00[s];
-            const bf16x8 t00 = *reinterpret_cast<const bf16x8*>(t);
-            const bf16x8 t01 = *reinterpret_cast<const bf16x8*>(t + ldx[s]);
-            const bf16x8 t10 = *reinterpret_cast<const bf16x8*>(t + ldy[s]);
-            const bf16x8 t11 = *reinterpret_cast<const bf16x8*>(t + ldy[s] + ldx[s]);
+            // 4 taps x 8 channels: v_perm_b32 pairs the same channel of two taps, v_dot2c_f32_bf16 applies both weights
+            const uint4 t00 = *reinterpret_cast<const uint4*>(t);
+            const uint4 t01 = *reinterpret_cast<const uint4*>(t + ldx[s]);
+            const uint4 t10 = *reinterpret_cast<const uint4*>(t + ldy[s]);
+            const uint4 t11 = *reinterpret_cast<const uint4*>(t + ldy[s] + ldx[s]);
+            const unsigned a0[4] = {t00.x, t00.y, t00.z, t00.w}, a1[4] = {t01.x, t01.y, t01.z, t01.w};
+            const unsigned b0[4] = {t10.x, t10.y, t10.z, t10.w}, b1[4] = {t11.x, t11.y, t11.z, t11.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                v[e] += (float)t00[e] * w00[s] + (float)t01[e] * w01[s] + (float)t10[e] * w10[s] + (float)t11[e] * w11[s];
+            for (int pr = 0; pr < 4; ++pr) {
+                const bf16x2 tl = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(a1[pr], a0[pr], 0x05040100u));
+                const bf16x2 th = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(a1[pr], a0[pr], 0x07060302u));
+                const bf16x2 bl = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(b1[pr], b0[pr], 0x05040100u));
+                const bf16x2 bh = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(b1[pr], b0[pr], 0x07060302u));
+                v[2 * pr] = __builtin_amdgcn_fdot2_f32_bf16(tl, wtop[s], v[2 * pr], false);
+                v[2 * pr] = __builtin_amdgcn_fdot2_f32_bf16(bl, wbot[s], v[2 * pr], false);
+                v[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(th, wtop[s], v[2 * pr + 1], false);
+                v[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(bh, wbot[s], v[2 * pr + 1], false);
+            }
         }
         bf16x8 bH;
 #pragma unroll

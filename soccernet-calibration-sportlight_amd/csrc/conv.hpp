@@ -29,11 +29,17 @@
 // weight chunk is a lane-linear copy; the halo tile is written as [pixel][SLOTS x 16 B] where lanes that
 // fall on the pitch padding, outside the image or beyond Cin fetch out of bounds and the buffer descriptor
 // returns zeros -- zero padding costs nothing.  Barriers are raw s_barrier + explicit s_waitcnt vmcnt so
-// that hipcc does not drain the DMA queue early.  Measured on MI355X the kernel is bound by the LDS-fill
-// staging ROUNDS (DMA issue + memory latency + barrier, ~2.5 us each, independent of the bytes moved: sharing a
-// weight chunk between two sub-tiles did not pay).  Two ways to hide a round are instantiated: ST == 1 relies
-// on a second resident workgroup per CU (LDS <= 80 KB), ST == 2 double-buffers the chunk inside the workgroup
-// (the next chunk's DMA is issued right after the per-chunk barrier and lands under the current MFMAs).
+// that hipcc does not drain the DMA queue early.
+//
+// What bounds the kernel (per-workgroup s_memtime traces, profiles/): a staging round is LATENCY-bound -- weights
+// are L2 hits (~58 B/clk/CU), the halo comes from HBM/Infinity Cache (2-3k clk under load) -- and a workgroup
+// that issues a round and then waits leaves the CU without MFMA work ~50 % of the time even with a second
+// resident workgroup.  PF selects how much of the next chunk is in flight under the current chunk's MFMAs:
+//   PF = 0  single buffers: issue chunk c, wait, multiply (single-chunk layers; big tiles)
+//   PF = 1  halo double-buffered: the HBM part of chunk c+1 is prefetched, the weight chunk (L2) is not
+//   PF = 2  halo and weights double-buffered: the whole of chunk c+1 is prefetched
+// with LDS = (PF == 2 ? 2 : 1) * weights + (PF >= 1 ? 2 : 1) * halo; the host picks (variant, tile, PF) per layer
+// so that two or three workgroups stay resident per CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -63,9 +69,9 @@ struct ConvParams {
     int tiles_x, tiles_y;
     int relu, out_f32;
     unsigned w_bytes;                // size of the packed weight buffer (buffer descriptor range)
-    int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA (results invalid)
-    int skew;                        // tuning aid: initial delay (x64 clk) of every second co-resident workgroup
+    int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA, bit2 skip weight DMA, bit3 skip halo DMA (results invalid)
     int epi_lds;                     // 1: transpose the output tile through LDS for 16-byte coalesced stores
+    unsigned long long* trace;       // tuning aid (SNCAL_CONV_TRACE): 16 timestamps per workgroup, or null
 };
 
 // pixel pitch (bytes) of the LDS halo tile that makes the B-fragment reads conflict-free
@@ -78,7 +84,17 @@ __host__ __device__ constexpr int halo_pitch(int G, int stride) {
     return slots * 16;
 }
 
+// pixel fragments per wave that the coalesced epilogue stages through LDS at a time
+__host__ __device__ constexpr int epi_frags(int NI, int wgs_per_cu) { return wgs_per_cu >= 3 ? 1 : NI > 4 ? 2 : NI; }
+
 __host__ __device__ constexpr int conv_nks(int KS, int G) { return (KS * KS * G + 3) / 4; }
+
+
+// workgroups per CU the kernel is compiled for: small weight chunks (<= 32 KB) with <= 18 accumulator tiles fit
+// three (168 VGPRs, <= 53 KB LDS) -- a staging round is latency-bound (~3k clk), more workgroups in flight hide it
+__host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G, int PF) {
+    return (conv_nks(KS, G) * MI * (PF == 2 ? 2 : 1) <= 32 && MI * NI <= 18) ? 3 : 2;
+}
 
 inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
     const int th = 4 * NI / twf;
@@ -90,8 +106,8 @@ inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int ST>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int PF>
+__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_kernel(const ConvParams p) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
     constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
@@ -110,21 +126,21 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int nb = blockIdx.y;
     const int TWF = p.twf, TH = 4 * NI / TWF;
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
-    constexpr int NT = 1;
     const int oy00 = ty * TH, ox0 = tx * 16 * TWF;
     const int ix0 = ox0 * STRIDE - PAD;
     const int g = lane >> 4, ln = lane & 15;
     const int npix = HALO_H * HALO_W;
     const int halo_bytes = (npix * PS + 1023) / 1024 * 1024;
-    const int stage_bytes = NKS * MI * 1024 + halo_bytes;
 
-    f32x4 acc[NT][MI][NI];
+    // accumulators start at the folded-BN shift of the lane's 4 output channels (no bias pass in the epilogue; the
+    // load latency hides under the first staging round)
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int mi = 0; mi < MI; ++mi) {
+        const float4 bs = *reinterpret_cast<const float4*>(p.bias + (nb * MI + mi) * 16 + g * 4);   // padded to nblk*MI*16, zeros beyond Cout
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[t][mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[mi][j] = f32x4{bs.x, bs.y, bs.z, bs.w};
+    }
 
     int boff[NI];
 #pragma unroll
@@ -142,44 +158,19 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int n_halo_instr = halo_bytes / 1024;
 
-    // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
-    // known up front, so the residual is requested now and arrives under the main loop
-    constexpr int EPI_CO = MI * 16, EPI_GROUPS = EPI_CO / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;
-    bf16x8 res_pf[NT][NI][EPI_ITERS];
-    const bool epi_a = GE == 8 && p.epi_lds && !p.out_f32;
-    if constexpr (GE == 8) {
-        if (epi_a && p.res) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int f = wave * NI + j;
-                    const int fr = f / TWF, fx = f - fr * TWF;
-                    const int oy = oy00 + t * TH + fr;
-#pragma unroll
-                    for (int it = 0; it < EPI_ITERS; ++it) {
-                        const int id = it * 64 + lane;
-                        const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
-                        const int ox = ox0 + fx * 16 + px;
-                        const int co = nb * EPI_CO + grp * 8;
-                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (id < EPI_ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout)
-                            r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) +
-                                (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co);
-                        res_pf[t][j][it] = r;
-                    }
-                }
-        }
-    }
-
-    auto issue_chunk = [&](int c, int stage) {
-        char* const sw = smem + stage * stage_bytes;
-        char* const si = sw + NKS * MI * 1024;
-        // weights: lane-linear 1 KB pieces, round-robin over the 4 waves
-        const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * (NKS * MI * 1024));
+    // LDS: [weights 0][weights 1 if PF == 2][halo 0][halo 1 if PF >= 1]
+    constexpr int W_BYTES = NKS * MI * 1024;
+    char* const s_halo0 = smem + (PF == 2 ? 2 : 1) * W_BYTES;
+    auto issue_weights = [&](int c, int buf) {   // lane-linear 1 KB pieces, round-robin over the 4 waves
+        if (p.ablate & 6) return;
+        const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * W_BYTES);
+        char* const sw = smem + buf * W_BYTES;
         for (int i = wave; i < NKS * MI; i += 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(sw + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
-        // halo: slot s of the [pixel][SLOTS] image; padding slots / outside-image pixels read out of range -> zeros
+    };
+    auto issue_halo = [&](int c, int buf) {      // slot s of the [pixel][SLOTS] image; padding slots and
+        if (p.ablate & 10) return;                // outside-image pixels read out of range -> zeros
+        char* const si = s_halo0 + buf * halo_bytes;
         const int iy0 = oy00 * STRIDE - PAD;
         const unsigned cbase = (unsigned)(c * G * 16);
         for (int j = wave; j < n_halo_instr; j += 4) {
@@ -194,25 +185,55 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         }
     };
 
-    if (p.skew > 0 && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {      // de-phase the two workgroups of a CU
-        for (int k = 0; k < p.skew; ++k) __builtin_amdgcn_s_sleep(16);
+    unsigned long long* const trc = p.trace ? p.trace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 : nullptr;
+    auto stamp = [&](int slot) { if (trc && tid == 0 && slot < 16) trc[slot] = __builtin_amdgcn_s_memtime(); };
+    if (trc && tid == 0) trc[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    stamp(1);
+    issue_weights(0, 0); issue_halo(0, 0);      // chunk 0 first: everything below until the wait is free
+
+    // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
+    // known up front, so the residual is requested now and arrives under the main loop
+    constexpr int EPI_CO = MI * 16, EPI_GROUPS = EPI_CO / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;
+    constexpr bool RES_PF = MI * NI <= 24 && conv_wgs_per_cu(KS, NI, MI, G, PF) == 2;   // big accumulator sets leave no registers for the prefetch
+    bf16x8 res_pf[RES_PF ? NI : 1][EPI_ITERS];
+    const bool epi_a = GE == 8 && p.epi_lds && !p.out_f32;
+    if constexpr (GE == 8 && RES_PF) {
+        if (epi_a && p.res) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int f = wave * NI + j;
+                    const int fr = f / TWF, fx = f - fr * TWF;
+                    const int oy = oy00 + fr;
+#pragma unroll
+                    for (int it = 0; it < EPI_ITERS; ++it) {
+                        const int id = it * 64 + lane;
+                        const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
+                        const int ox = ox0 + fx * 16 + px;
+                        const int co = nb * EPI_CO + grp * 8;
+                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (id < EPI_ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout)
+                            r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) +
+                                (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co);
+                        res_pf[j][it] = r;
+                    }
+                }
+        }
     }
-    if (ST == 2 && !(p.ablate & 2)) issue_chunk(0, 0);
+
     for (int c = 0; c < p.cin_chunks; ++c) {
-      constexpr int t = 0;
-      {
-        const int stage = ST == 2 ? (c & 1) : 0;
-        if constexpr (ST == 1) {
-            if (c > 0) asm volatile("s_barrier" ::: "memory");           // everyone finished reading the buffers
-            if (!(p.ablate & 2)) issue_chunk(c, 0);
+        if (PF == 0 && c > 0) {
+            asm volatile("s_barrier" ::: "memory");                       // everyone finished reading the buffers
+            issue_weights(c, 0); issue_halo(c, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // my pieces of chunk c have landed
-        asm volatile("s_barrier" ::: "memory");                           // ... everyone's; compute(c-1) is over
-        if constexpr (ST == 2) {
-            if (c + 1 < p.cin_chunks && !(p.ablate & 2)) issue_chunk(c + 1, stage ^ 1);   // lands under chunk c's MFMAs
+        asm volatile("s_barrier" ::: "memory");                           // ... everyone's; the MFMAs of chunk c-1 are over
+        stamp(2 + 2 * c);
+        if (PF > 0 && c + 1 < p.cin_chunks) {                             // lands under the MFMAs of chunk c
+            issue_halo(c + 1, (c + 1) & 1);
+            if (PF == 2) issue_weights(c + 1, (c + 1) & 1);
         }
-        const char* const s_w = smem + stage * stage_bytes;
-        const char* const s_in = s_w + NKS * MI * 1024;
+        const char* const s_w = smem + (PF == 2 ? (c & 1) * W_BYTES : 0);
+        const char* const s_in = s_halo0 + (PF > 0 ? (c & 1) * halo_bytes : 0);
         // fragment offsets of k-step s (compile-time tap arithmetic when the 4 k-groups of a step share a tap)
         auto frag_off = [&](int s) -> int {
             if constexpr (G % 4 == 0) {
@@ -226,7 +247,46 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
                 return dy * row_pitch + dx * PS + cg * 16;
             }
         };
-        if (p.ablate & 1) continue;
+        if (!(p.ablate & 1)) {
+        auto mma = [&](f32x4& d, const frag& av, const frag& bv) {
+            if constexpr (GE == 8) {
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, d, 0, 0, 0);
+            } else {
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], d, 0, 0, 0);
+            }
+        };
+        if constexpr (MI * NI > 24) {
+            // large register tiles: pixel fragments of step s+1 are fetched while step s multiplies, the weight
+            // fragments stream one at a time (one fetched ahead) -- a full second fragment set would spill
+            frag b[2][NI], a_cur, a_nxt;
+            {
+                const int off = frag_off(0);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[0][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+                a_cur = *reinterpret_cast<const frag*>(s_w + lane * 16);
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s + 1 < NKS) {
+                    const int off = frag_off(s + 1);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) b[nxt][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int nidx = s * MI + mi + 1;
+                    if (nidx < NKS * MI) a_nxt = *reinterpret_cast<const frag*>(s_w + (nidx * 64 + lane) * 16);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mma(acc[mi][j], a_cur, b[cur][j]);
+                    a_cur = a_nxt;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
         // software pipeline over k-steps: fragments of step s+1 are fetched from LDS while step s multiplies
         frag a[2][MI], b[2][NI];
         {
@@ -250,22 +310,19 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if constexpr (GE == 8) {
-                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mi], b[cur][j], acc[t][mi][j], 0, 0, 0);
-                    } else {
-                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][0], b[cur][j][0], acc[t][mi][j], 0, 0, 0);
-                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][1], b[cur][j][1], acc[t][mi][j], 0, 0, 0);
-                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][2], b[cur][j][2], acc[t][mi][j], 0, 0, 0);
-                        acc[t][mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][mi][3], b[cur][j][3], acc[t][mi][j], 0, 0, 0);
-                    }
-                }
+                for (int j = 0; j < NI; ++j) mma(acc[mi][j], a[cur][mi], b[cur][j]);
             if (s + 1 < NKS) __builtin_amdgcn_sched_barrier(0);    // keep the prefetch ahead of the next step's MFMAs
         }
-      }
+        }
+        }
+        stamp(3 + 2 * c);
+        if (PF == 1 && c + 1 < p.cin_chunks) {                            // single weight buffer: refill once everyone is done with it
+            asm volatile("s_barrier" ::: "memory");
+            issue_weights(c + 1, 0);
+        }
     }
 
-    // ---- epilogue A (bf16 outputs): + folded-BN shift in the MFMA layout, transpose through LDS (the staging
+    // ---- epilogue A (bf16 outputs): transpose through LDS (the staging
     // buffers are free now), then every lane handles 8 consecutive channels of one pixel: residual load and
     // output store are 16 bytes per lane and contiguous per pixel row (a fragment row is one 16 x Cout*2 B
     // contiguous span) instead of 8-byte pieces scattered over 16 pixel rows.
@@ -273,26 +330,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
         if (epi_a) {
             constexpr int CO = MI * 16, PITCH = CO + 4;                   // floats per staged pixel row
             asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
-            float* stg = reinterpret_cast<float*>(smem) + wave * (NI * 16 * PITCH);
+            stamp(10);
+            constexpr int JB = epi_frags(NI, conv_wgs_per_cu(KS, NI, MI, G, PF));                              // fragments staged at a time
+            float* stg = reinterpret_cast<float*>(smem) + wave * (JB * 16 * PITCH);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int j0 = 0; j0 < NI; j0 += JB) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const int co = (nb * MI + mi) * 16 + g * 4;
-                        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (nb * MI + mi < p.cout_frags) bs = *reinterpret_cast<const float4*>(p.bias + co);
-                        *reinterpret_cast<float4*>(stg + (j * 16 + ln) * PITCH + mi * 16 + g * 4) =
-                            make_float4(acc[t][mi][j][0] + bs.x, acc[t][mi][j][1] + bs.y, acc[t][mi][j][2] + bs.z, acc[t][mi][j][3] + bs.w);
+                        const int j = j0 + jj;
+                        *reinterpret_cast<float4*>(stg + (jj * 16 + ln) * PITCH + mi * 16 + g * 4) =
+                            make_float4(acc[mi][j][0], acc[mi][j][1], acc[mi][j][2], acc[mi][j][3]);
                     }
                 // wave-local hand-off: LDS operations of one wave complete in order
+                if (j0 == 0) stamp(11);
                 constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
+                for (int jj = 0; jj < JB; ++jj) {
+                    const int j = j0 + jj;
                     const int f = wave * NI + j;
                     const int fr = f / TWF, fx = f - fr * TWF;
-                    const int oy = oy00 + t * TH + fr;
+                    const int oy = oy00 + fr;
 #pragma unroll
                     for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
                         const int id = it * 64 + lane;
@@ -300,13 +359,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
                         const int ox = ox0 + fx * 16 + px;
                         const int co = nb * CO + grp * 8;
                         if (id < ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout) {
-                            const float* sp = stg + (j * 16 + px) * PITCH + grp * 8;
+                            const float* sp = stg + (jj * 16 + px) * PITCH + grp * 8;
                             const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
                             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                             const size_t o = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
                             if (p.res) {
+                                bf16x8 r;
+                                if constexpr (RES_PF) r = res_pf[j][it];
+                                else r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) + o);
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += (float)res_pf[t][j][it][e];
+                                for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
                             }
                             bf16x8 q;
 #pragma unroll
@@ -316,17 +378,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
                     }
                 }
             }
+            stamp(15);
             return;
         }
     }
-    // epilogue: + folded-BN shift (+ residual) (ReLU) -> store 4 consecutive channels per lane
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
+    // epilogue: (+ residual) (ReLU) -> store 4 consecutive channels per lane
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int f = wave * NI + j;
         const int fr = f / TWF, fx = f - fr * TWF;
-        const int oy = oy00 + t * TH + fr, ox = ox0 + fx * 16 + ln;
+        const int oy = oy00 + fr, ox = ox0 + fx * 16 + ln;
         if (oy >= p.Hout || ox >= p.Wout) continue;
         const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
@@ -335,9 +396,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             if (cf >= p.cout_frags) continue;
             const int co = cf * 16 + g * 4;
             if (co >= p.cout) continue;                    // padded output channels are never stored
-            const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
-            float v0 = acc[t][mi][j][0] + bs.x, v1 = acc[t][mi][j][1] + bs.y;
-            float v2 = acc[t][mi][j][2] + bs.z, v3 = acc[t][mi][j][3] + bs.w;
+            float v0 = acc[mi][j][0], v1 = acc[mi][j][1], v2 = acc[mi][j][2], v3 = acc[mi][j][3];
             const size_t o = pix * p.out_cstride + p.out_coff + co;
             if (p.res) {
                 if constexpr (GE == 8) {
@@ -368,18 +427,18 @@ typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
-    ConvLaunchFn launch1, launch2;   // ST = 1 (single stage) / ST = 2 (double-buffered chunks)
+    ConvLaunchFn launch[3];          // PF = 0, 1, 2 (prefetch depth, see the header)
 };
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int ST>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G, int PF>
 void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, ST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, ST>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, PF>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

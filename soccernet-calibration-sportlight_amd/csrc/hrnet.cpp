@@ -572,17 +572,18 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
     // pick NI / tile shape / sub-tiles per weight chunk for this spatial size
     const ConvVariant* bestv = nullptr;
-    int best_twf = 1, best_nt = 1; double best_score = -1; size_t best_lds = 0;
+    int best_twf = 1, best_pf = 0; double best_score = -1; size_t best_lds = 0;
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
-    static const int force_nt = getenv("SNCAL_FORCE_ST") ? atoi(getenv("SNCAL_FORCE_ST")) : 0;
-    static const double st2_two = getenv("SNCAL_ST2_TWO") ? atof(getenv("SNCAL_ST2_TWO")) : 1.05;
-    static const double three_cu = getenv("SNCAL_THREE_CU") ? atof(getenv("SNCAL_THREE_CU")) : 1.0;
-    static const double st2_one = getenv("SNCAL_ST2_ONE") ? atof(getenv("SNCAL_ST2_ONE")) : 0.8;
+    static const int force_pf = getenv("SNCAL_FORCE_PF") ? atoi(getenv("SNCAL_FORCE_PF")) : -1;
+    static const double three_gain = getenv("SNCAL_THREE_GAIN") ? atof(getenv("SNCAL_THREE_GAIN")) : 1.15;
+    static const double pf1_gain = getenv("SNCAL_PF1_GAIN") ? atof(getenv("SNCAL_PF1_GAIN")) : 1.1;
+    static const double pf2_gain = getenv("SNCAL_PF2_GAIN") ? atof(getenv("SNCAL_PF2_GAIN")) : 1.2;
     bool has_forced = false;
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks == L.k && V.stride == L.stride && V.mi == L.mi && V.g == L.g && V.ni == force_ni) has_forced = true;
     }
+    for (int pass = 0; pass < 2 && !bestv; ++pass)          // pass 1: the tuning knobs excluded everything -> ignore them
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride || V.mi != L.mi || V.g != L.g) continue;
@@ -594,22 +595,21 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
             const int th = F / twf;
             const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
             if (lds > 160 * 1024) continue;
-            for (int nt = 1; nt <= 2; ++nt) {                                     // nt = staging depth ST
-                if (force_nt && nt != force_nt && !(force_nt == 2 && L.chunks < 2)) continue;
-                if (nt == 2 && L.chunks < 2) continue;
-                const size_t lds_t = lds * nt;
+            for (int pf = 0; pf < 3; ++pf) {                                      // prefetch depth (conv.hpp header)
+                if (pass == 0 && force_pf >= 0 && pf != force_pf && L.chunks > 1) continue;
+                if (pf > 0 && L.chunks < 2) continue;
+                const size_t lds_t = wchunk * (pf == 2 ? 2 : 1) + (lds - wchunk) * (pf >= 1 ? 2 : 1);
                 if (lds_t > 160 * 1024) continue;
                 const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
                 const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
                 const long blocks = ty * tx * sb * L.nblk;
-                const int per_cu = (int)std::min<size_t>(3, (160 * 1024) / lds_t);
+                const int per_cu = (int)std::min<size_t>(conv_wgs_per_cu(V.ks, V.ni, V.mi, V.g, pf), (160 * 1024) / lds_t);
                 const double fill = std::min(1.0, (double)blocks / (256.0 * per_cu));
                 const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
-                // a staging round (DMA issue + latency + barrier) is hidden by a second resident workgroup (ST1)
-                // or by the workgroup's own second stage (ST2); calibrated on MI355X, see profiles/
-                const double overlap = nt == 1 ? (per_cu >= 3 ? three_cu : per_cu >= 2 ? 1.0 : 0.55) : (per_cu >= 2 ? st2_two : st2_one);
+                // exposed staging latency: hidden by co-resident workgroups and by the prefetch depth
+                const double overlap = (per_cu >= 3 ? three_gain : per_cu >= 2 ? 1.0 : 0.55) * (pf == 0 ? 1.0 : pf == 1 ? pf1_gain : pf2_gain);
                 const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap;
-                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds_t; best_nt = nt; }
+                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds_t; best_pf = pf; }
             }
         }
     }
@@ -621,21 +621,36 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     {   // LDS-transposed epilogue: the fp32 tile of the 4 waves is staged in the (grown, if that keeps two
         // workgroups per CU) dynamic LDS; needs whole 8-channel groups
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
-        const size_t need = (size_t)4 * bestv->ni * 16 * (L.mi * 16 + 4) * 4;
+        const int wgs = conv_wgs_per_cu(L.k, bestv->ni, L.mi, L.g, best_pf);
+        const size_t need = (size_t)4 * epi_frags(bestv->ni, wgs) * 16 * (L.mi * 16 + 4) * 4;
         const bool shape_ok = net.dtype == SNCAL_BF16 && !op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0;
-        const bool fits = need <= best_lds || (need <= 80 * 1024 && best_lds <= 80 * 1024) || need <= 52 * 1024;
+        const size_t now_per_cu = std::min<size_t>(wgs, (160 * 1024) / best_lds);
+        const bool fits = need <= best_lds || need <= (160 * 1024) / now_per_cu || need <= 52 * 1024;
         p.epi_lds = (epi && shape_ok && fits) ? 1 : 0;
         if (p.epi_lds && need > best_lds) best_lds = need;
     }
-    { static const int sk = getenv("SNCAL_SKEW") ? atoi(getenv("SNCAL_SKEW")) : 0; p.skew = sk; }
     { static const int abl = getenv("SNCAL_ABLATE") ? atoi(getenv("SNCAL_ABLATE")) : 0; p.ablate = abl; }
     p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
     { static const int extra = getenv("SNCAL_EXTRA_LDS") ? atoi(getenv("SNCAL_EXTRA_LDS")) : 0; best_lds = std::min<size_t>(best_lds + extra, 160 * 1024); }
-    (best_nt == 2 ? bestv->launch2 : bestv->launch1)(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
+    static const char* trace_name = getenv("SNCAL_CONV_TRACE");
+    unsigned long long* d_trace = nullptr; size_t n_trace = 0;
+    if (trace_name && L.name == trace_name) {
+        n_trace = (size_t)p.tiles_x * p.tiles_y * sb * L.nblk * 16;
+        if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
+    }
+    bestv->launch[best_pf](p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
+    if (d_trace) {
+        std::vector<unsigned long long> h(n_trace);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_trace, n_trace * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (FILE* f = fopen(getenv("SNCAL_CONV_TRACE_FILE") ? getenv("SNCAL_CONV_TRACE_FILE") : "conv_trace.bin", "wb")) { fwrite(h.data(), 8, n_trace, f); fclose(f); }
+    }
     if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,ST%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
-                              bestv->ni, L.mi, L.g, best_nt);
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,PF%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+                              bestv->ni, L.mi, L.g, best_pf);
         const double px = (double)sb * to.H * to.W;
         net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
         net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +

@@ -90,6 +90,19 @@ __host__ __device__ constexpr int epi_frags(int NI, int wgs_per_cu) { return wgs
 __host__ __device__ constexpr int conv_nks(int KS, int G) { return (KS * KS * G + 3) / 4; }
 
 
+// upper bound of the 1 KB halo pieces of a tile, over the tile shapes the host may pick (TWF = 1, 2, 4, ...)
+__host__ __device__ constexpr int conv_max_halo_pieces(int KS, int S, int NI, int G) {
+    int best = 0;
+    for (int twf = 1; twf <= 4 * NI; twf *= 2) {
+        if ((4 * NI) % twf) continue;
+        const int th = 4 * NI / twf;
+        const int hh = (th - 1) * S + KS, hw = (16 * twf - 1) * S + KS;
+        const int pieces = (hh * hw * halo_pitch(G, S) + 1023) / 1024;
+        if (pieces <= 64 && pieces > best) best = pieces;      // tiles above 64 KB of halo are never chosen
+    }
+    return best;
+}
+
 // workgroups per CU the kernel is compiled for: small weight chunks (<= 32 KB) with <= 18 accumulator tiles fit
 // three (168 VGPRs, <= 53 KB LDS) -- a staging round is latency-bound (~3k clk), more workgroups in flight hide it
 __host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G, int PF) {
@@ -168,20 +181,53 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
         for (int i = wave; i < NKS * MI; i += 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(sw + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
     };
-    auto issue_halo = [&](int c, int buf) {      // slot s of the [pixel][SLOTS] image; padding slots and
-        if (p.ablate & 10) return;                // outside-image pixels read out of range -> zeros
+    issue_weights(0, 0);      // chunk 0's weights first: the address arithmetic below runs under their flight
+
+    // Halo pieces: piece j covers 64 consecutive 16-byte slots of the [pixel][SLOTS] image.  A lane's global
+    // offset does not depend on the chunk (the chunk's channel offset rides in the scalar offset), so the
+    // address arithmetic (two divisions, bounds tests) is done ONCE per workgroup and kept in registers: while a
+    // co-resident wave runs MFMAs a VALU instruction issues every ~8 clk, and recomputing ~60 of them per piece
+    // per chunk was the longest part of a staging round (per-workgroup trace, profiles/).  Padding slots and
+    // outside-image pixels get an out-of-range offset -> the DMA writes zeros.
+    // (Kept for register tiles that leave room: <= 8 pieces per wave, <= 18 accumulator tiles.)
+    constexpr int MAXH_ALL = (conv_max_halo_pieces(KS, STRIDE, NI, G) + 3) / 4;
+    constexpr bool HOIST = MAXH_ALL <= 8 && MI * NI <= 18;
+    constexpr int MAXH = HOIST ? MAXH_ALL : 1;
+    const int cin_groups = (p.Cin + GE - 1) / GE;
+    auto halo_voff = [&](int j, int c_lo) -> unsigned {      // c_lo: first k-group of the chunk, or 0 when hoisted
+        const int slot = j * 64 + lane;
+        const int pix = slot / SLOTS, cg = slot - pix * SLOTS;
+        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        const int iy = oy00 * STRIDE - PAD + hy, ix = ix0 + hx;
+        const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c_lo + cg < cin_groups;
+        return ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
+    };
+    unsigned hv[MAXH];
+    if (HOIST) {
+#pragma unroll
+        for (int jj = 0; jj < MAXH; ++jj) hv[jj] = halo_voff(wave + 4 * jj, 0);
+    }
+    const bool has_tail = cin_groups % G != 0;       // last chunk holds fewer than G k-groups per pixel
+    auto issue_halo = [&](int c, int buf) {
+        if (p.ablate & 10) return;
         char* const si = s_halo0 + buf * halo_bytes;
-        const int iy0 = oy00 * STRIDE - PAD;
         const unsigned cbase = (unsigned)(c * G * 16);
-        for (int j = wave; j < n_halo_instr; j += 4) {
-            const int slot = j * 64 + lane;
-            const int pix = slot / SLOTS, cg = slot - pix * SLOTS;
-            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win &&
-                            (c * G + cg) * GE < p.Cin;
-            const unsigned voff = ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(si + j * 1024), 16, voff, cbase, 0, 0);
+        if (HOIST) {
+            const bool tail = has_tail && c == p.cin_chunks - 1;
+#pragma unroll
+            for (int jj = 0; jj < MAXH; ++jj) {
+                const int j = wave + 4 * jj;
+                if (j < n_halo_instr) {
+                    unsigned voff = hv[jj];
+                    if (tail) { const int slot = j * 64 + lane; if (c * G + slot % SLOTS >= cin_groups) voff = 0x80000000u; }
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(si + j * 1024), 16, voff, cbase, 0, 0);
+                }
+            }
+        } else {
+            for (int j = wave; j < n_halo_instr; j += 4) {
+                const unsigned voff = halo_voff(j, c * G);   // (a call inside the builtin's arguments loses the host stub)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(si + j * 1024), 16, voff, cbase, 0, 0);
+            }
         }
     };
 
@@ -189,7 +235,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     auto stamp = [&](int slot) { if (trc && tid == 0 && slot < 16) trc[slot] = __builtin_amdgcn_s_memtime(); };
     if (trc && tid == 0) trc[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
     stamp(1);
-    issue_weights(0, 0); issue_halo(0, 0);      // chunk 0 first: everything below until the wait is free
+    issue_halo(0, 0);         // chunk 0 is in flight: everything below until the wait is free
 
     // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
     // known up front, so the residual is requested now and arrives under the main loop
@@ -224,8 +270,10 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
         if (PF == 0 && c > 0) {
             asm volatile("s_barrier" ::: "memory");                       // everyone finished reading the buffers
             issue_weights(c, 0); issue_halo(c, 0);
+            if (c == 1) stamp(12);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // my pieces of chunk c have landed
+        if (c == 1) stamp(13);
         asm volatile("s_barrier" ::: "memory");                           // ... everyone's; the MFMAs of chunk c-1 are over
         stamp(2 + 2 * c);
         if (PF > 0 && c + 1 < p.cin_chunks) {                             // lands under the MFMAs of chunk c

@@ -594,7 +594,7 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
             if (F % twf) continue;
             const int th = F / twf;
             const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
-            if (lds > 160 * 1024) continue;
+            if (lds > 160 * 1024 || lds - wchunk > 64 * 1024) continue;   // halo tiles are capped at 64 DMA pieces
             for (int pf = 0; pf < 3; ++pf) {                                      // prefetch depth (conv.hpp header)
                 if (pass == 0 && force_pf >= 0 && pf != force_pf && L.chunks > 1) continue;
                 if (pf > 0 && L.chunks < 2) continue;

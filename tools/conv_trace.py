@@ -17,6 +17,8 @@ hw = (a[:, 0] >> np.uint64(32)).astype(np.int64); xcc = (a[:, 0] & np.uint64(0xf
 cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (xcc << 8)
 if T[:, 9].max() > 0:
     print(' epilogue: barrier %d, bias+stage writes %d, rest %d' % (int((T[:, 9] - prev).mean()), int((T[:, 10] - T[:, 9]).mean()), int((end - T[:, 10]).mean())))
+if T[:, 11].max() > 0:
+    print(' chunk 1 round: barrier+issue %d, vmcnt wait %d, barrier %d' % (int((T[:, 11] - T[:, 2]).mean()), int((T[:, 12] - T[:, 11]).mean()), int((T[:, 3] - T[:, 12]).mean())))
 print(' distinct CUs', len(np.unique(cu)))
 # overlap on one CU: fraction of a WG's mfma time during which another WG on the same CU is also in an mfma phase
 tot = both = 0

@@ -66,6 +66,7 @@ struct ConvParams {
     int out_cstride, out_coff;
     int cin_chunks;
     int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
+    unsigned halo_w_magic;           // floor(2^32 / halo width) + 1: pix / halo_w == umulhi(pix, magic) for pix < 2^16
     int tiles_x, tiles_y;
     int relu, out_f32;
     unsigned w_bytes;                // size of the packed weight buffer (buffer descriptor range)
@@ -195,11 +196,14 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     constexpr int MAXH = HOIST ? MAXH_ALL : 1;
     const int cin_groups = (p.Cin + GE - 1) / GE;
     auto halo_voff = [&](int j, int c_lo) -> unsigned {      // c_lo: first k-group of the chunk, or 0 when hoisted
-        const int slot = j * 64 + lane;
-        const int pix = slot / SLOTS, cg = slot - pix * SLOTS;
-        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        const int iy = oy00 * STRIDE - PAD + hy, ix = ix0 + hx;
-        const bool ok = cg < G && pix < npix && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c_lo + cg < cin_groups;
+        // branch-free, divisions by multiplication (pix < 2^16): every VALU instruction here competes with a
+        // co-resident wave's MFMA issue
+        const unsigned slot = (unsigned)(j * 64 + lane);
+        const unsigned pix = slot / (unsigned)SLOTS, cg = slot - pix * SLOTS;
+        const unsigned hy = __umulhi(pix, p.halo_w_magic), hx = pix - hy * HALO_W;
+        const int iy = oy00 * STRIDE - PAD + (int)hy, ix = ix0 + (int)hx;
+        const bool ok = (cg < (unsigned)G) & (pix < (unsigned)npix) & ((unsigned)iy < (unsigned)p.Hin) &
+                        ((unsigned)ix < (unsigned)p.Win) & ((int)(c_lo + cg) < cin_groups);
         return ok ? (unsigned)(((iy * p.Win + ix) * p.Cin) * ESIZE + cg * 16) : 0x80000000u;
     };
     unsigned hv[MAXH];

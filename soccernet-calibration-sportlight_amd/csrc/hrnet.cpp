@@ -361,7 +361,9 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         if (V.ks != L.k || V.stride != L.stride) continue;
         if (force_mi && L.k == 3 && L.stride == 1 && V.mi != force_mi && cout_frags % force_mi == 0) continue;
         { static const int force_g = getenv("SNCAL_FORCE_G") ? atoi(getenv("SNCAL_FORCE_G")) : 0;
-          if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue; }
+          if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue;
+          static const int force_g48 = getenv("SNCAL_FORCE_G48") ? atoi(getenv("SNCAL_FORCE_G48")) : 0;
+          if (force_g48 && L.k == 3 && L.stride == 1 && L.cin_phys == 48 && L.cout == 48 && V.g != force_g48) continue; }
         const int chunks = (L.cin_phys + V.g * ge - 1) / (V.g * ge);
         const int nks = conv_nks(V.ks, V.g);
         const double k_eff = (double)(L.k * L.k * L.cin_phys / ge) / (double)(chunks * nks * 4);
@@ -616,6 +618,7 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
     const int th = 4 * bestv->ni / best_twf;
     p.twf = best_twf;
+    p.halo_w_magic = 0xFFFFFFFFu / (unsigned)((16 * best_twf - 1) * L.stride + L.k) + 1u;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;
     {   // LDS-transposed epilogue: the fp32 tile of the 4 waves is staged in the (grown, if that keeps two

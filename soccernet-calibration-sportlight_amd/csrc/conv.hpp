@@ -104,10 +104,21 @@ __host__ __device__ constexpr int conv_max_halo_pieces(int KS, int S, int NI, in
     return best;
 }
 
-// workgroups per CU the kernel is compiled for: small weight chunks (<= 32 KB) with <= 18 accumulator tiles fit
-// three (168 VGPRs, <= 53 KB LDS) -- a staging round is latency-bound (~3k clk), more workgroups in flight hide it
+// waves per SIMD the kernel is compiled for (HIP's second __launch_bounds__ argument; 2 -> 256 VGPRs, 3 -> 168):
+// small weight chunks (<= 32 KB) with <= 18 accumulator tiles fit three workgroups per CU (<= 53 KB LDS each) --
+// a staging round is latency-bound (~3k clk), more workgroups in flight hide it.  (A fifth, DMA-only producer
+// wave per workgroup was tried: two 5-wave workgroups only co-reside on a CU at <= 128 VGPRs -- wave placement
+// starts at the same SIMD -- which this register tile cannot meet.)
 __host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G, int PF) {
     return (conv_nks(KS, G) * MI * (PF == 2 ? 2 : 1) <= 32 && MI * NI <= 18) ? 3 : 2;
+}
+
+// workgroups per CU / epilogue staging depth of a variant (host and device agree through these)
+__host__ __device__ constexpr int conv_resident_wgs(int KS, int NI, int MI, int G, int PF) {
+    return conv_wgs_per_cu(KS, NI, MI, G, PF);
+}
+__host__ __device__ constexpr int conv_epi_frags(int KS, int NI, int MI, int G, int PF) {
+    return epi_frags(NI, conv_resident_wgs(KS, NI, MI, G, PF));
 }
 
 inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     // LDS: [weights 0][weights 1 if PF == 2][halo 0][halo 1 if PF >= 1]
     constexpr int W_BYTES = NKS * MI * 1024;
     char* const s_halo0 = smem + (PF == 2 ? 2 : 1) * W_BYTES;
-    auto issue_weights = [&](int c, int buf) {   // lane-linear 1 KB pieces, round-robin over the 4 waves
+    auto issue_weights = [&](int c, int buf) {   // lane-linear 1 KB pieces, round-robin over the issuing waves
         if (p.ablate & 6) return;
         const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * W_BYTES);
         char* const sw = smem + buf * W_BYTES;
@@ -310,35 +321,6 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], d, 0, 0, 0);
             }
         };
-        if constexpr (MI * NI > 24) {
-            // large register tiles: pixel fragments of step s+1 are fetched while step s multiplies, the weight
-            // fragments stream one at a time (one fetched ahead) -- a full second fragment set would spill
-            frag b[2][NI], a_cur, a_nxt;
-            {
-                const int off = frag_off(0);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[0][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
-                a_cur = *reinterpret_cast<const frag*>(s_w + lane * 16);
-            }
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < NKS) {
-                    const int off = frag_off(s + 1);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) b[nxt][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int nidx = s * MI + mi + 1;
-                    if (nidx < NKS * MI) a_nxt = *reinterpret_cast<const frag*>(s_w + (nidx * 64 + lane) * 16);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mma(acc[mi][j], a_cur, b[cur][j]);
-                    a_cur = a_nxt;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else {
         // software pipeline over k-steps: fragments of step s+1 are fetched from LDS while step s multiplies
         frag a[2][MI], b[2][NI];
         {
@@ -366,7 +348,6 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
             if (s + 1 < NKS) __builtin_amdgcn_sched_barrier(0);    // keep the prefetch ahead of the next step's MFMAs
         }
         }
-        }
         stamp(3 + 2 * c);
         if (PF == 1 && c + 1 < p.cin_chunks) {                            // single weight buffer: refill once everyone is done with it
             asm volatile("s_barrier" ::: "memory");
@@ -383,10 +364,38 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
             constexpr int CO = MI * 16, PITCH = CO + 4;                   // floats per staged pixel row
             asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
             stamp(10);
-            constexpr int JB = epi_frags(NI, conv_wgs_per_cu(KS, NI, MI, G, PF));                              // fragments staged at a time
+            constexpr int JB = conv_epi_frags(KS, NI, MI, G, PF);                              // fragments staged at a time
             float* stg = reinterpret_cast<float*>(smem) + wave * (JB * 16 * PITCH);
+            constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS, EITERS = (ITEMS + 63) / 64;
+            const size_t img_out = (size_t)n * p.Hout * p.Wout * p.out_cstride;
+            const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
+            __bf16* const out_img = reinterpret_cast<__bf16*>(p.out) + img_out;
 #pragma unroll
             for (int j0 = 0; j0 < NI; j0 += JB) {
+                // item -> (pixel, 8-channel group) offsets of this block; the residual (when it was not prefetched
+                // before the main loop) is requested for the whole block first, so its latency is paid once
+                unsigned off[JB][EITERS];
+                bf16x8 rr[RES_PF ? 1 : JB][RES_PF ? 1 : EITERS];
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const int f = wave * NI + j0 + jj;
+                    const int fr = f / TWF, fx = f - fr * TWF;
+                    const int oy = oy00 + fr;
+#pragma unroll
+                    for (int it = 0; it < EITERS; ++it) {
+                        const int id = it * 64 + lane;
+                        const int px = id / GROUPS, grp = id - px * GROUPS;
+                        const int ox = ox0 + fx * 16 + px;
+                        const int co = nb * CO + grp * 8;
+                        const bool ok = (id < ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
+                        off[jj][it] = ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
+                        if constexpr (!RES_PF) {
+                            bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                            if (p.res && ok) r = *reinterpret_cast<const bf16x8*>(res_img + off[jj][it]);
+                            rr[jj][it] = r;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
@@ -397,35 +406,26 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
                     }
                 // wave-local hand-off: LDS operations of one wave complete in order
                 if (j0 == 0) stamp(11);
-                constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS;
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj) {
-                    const int j = j0 + jj;
-                    const int f = wave * NI + j;
-                    const int fr = f / TWF, fx = f - fr * TWF;
-                    const int oy = oy00 + fr;
 #pragma unroll
-                    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
-                        const int id = it * 64 + lane;
-                        const int px = id / GROUPS, grp = id - px * GROUPS;
-                        const int ox = ox0 + fx * 16 + px;
-                        const int co = nb * CO + grp * 8;
-                        if (id < ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout) {
+                    for (int it = 0; it < EITERS; ++it) {
+                        if (off[jj][it] != 0xFFFFFFFFu) {
+                            const int id = it * 64 + lane;
+                            const int px = id / GROUPS, grp = id - px * GROUPS;
                             const float* sp = stg + (jj * 16 + px) * PITCH + grp * 8;
                             const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
                             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                            const size_t o = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
                             if (p.res) {
                                 bf16x8 r;
-                                if constexpr (RES_PF) r = res_pf[j][it];
-                                else r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) + o);
+                                if constexpr (RES_PF) r = res_pf[j0 + jj][it]; else r = rr[jj][it];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
                             }
                             bf16x8 q;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) q[e] = (__bf16)(p.relu ? fmaxf(v[e], 0.f) : v[e]);
-                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o) = q;
+                            *reinterpret_cast<bf16x8*>(out_img + off[jj][it]) = q;
                         }
                     }
                 }

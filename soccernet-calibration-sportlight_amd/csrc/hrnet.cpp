@@ -605,7 +605,7 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
                 const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
                 const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
                 const long blocks = ty * tx * sb * L.nblk;
-                const int per_cu = (int)std::min<size_t>(conv_wgs_per_cu(V.ks, V.ni, V.mi, V.g, pf), (160 * 1024) / lds_t);
+                const int per_cu = (int)std::min<size_t>(conv_resident_wgs(V.ks, V.ni, V.mi, V.g, pf), (160 * 1024) / lds_t);
                 const double fill = std::min(1.0, (double)blocks / (256.0 * per_cu));
                 const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
                 // exposed staging latency: hidden by co-resident workgroups and by the prefetch depth
@@ -624,8 +624,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     {   // LDS-transposed epilogue: the fp32 tile of the 4 waves is staged in the (grown, if that keeps two
         // workgroups per CU) dynamic LDS; needs whole 8-channel groups
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
-        const int wgs = conv_wgs_per_cu(L.k, bestv->ni, L.mi, L.g, best_pf);
-        const size_t need = (size_t)4 * epi_frags(bestv->ni, wgs) * 16 * (L.mi * 16 + 4) * 4;
+        const int wgs = conv_resident_wgs(L.k, bestv->ni, L.mi, L.g, best_pf);
+        const size_t need = (size_t)4 * conv_epi_frags(L.k, bestv->ni, L.mi, L.g, best_pf) * 16 * (L.mi * 16 + 4) * 4;
         const bool shape_ok = net.dtype == SNCAL_BF16 && !op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0;
         const size_t now_per_cu = std::min<size_t>(wgs, (160 * 1024) / best_lds);
         const bool fits = need <= best_lds || need <= (160 * 1024) / now_per_cu || need <= 52 * 1024;
@@ -635,6 +635,9 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     { static const int abl = getenv("SNCAL_ABLATE") ? atoi(getenv("SNCAL_ABLATE")) : 0; p.ablate = abl; }
     p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
     { static const int extra = getenv("SNCAL_EXTRA_LDS") ? atoi(getenv("SNCAL_EXTRA_LDS")) : 0; best_lds = std::min<size_t>(best_lds + extra, 160 * 1024); }
+    { static const bool dbg = getenv("SNCAL_CONV_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[conv] %-44s %dx%d cin %d cout %d: NI%d MI%d G%d PF%d twf %d lds %zu grid %dx%d epi_lds %d\n", L.name.c_str(), to.H, to.W, L.cin, L.cout,
+                       bestv->ni, L.mi, L.g, best_pf, best_twf, best_lds, p.tiles_x * p.tiles_y * sb, L.nblk, p.epi_lds); }
     // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
     static const char* trace_name = getenv("SNCAL_CONV_TRACE");
     unsigned long long* d_trace = nullptr; size_t n_trace = 0;

@@ -16,7 +16,7 @@ x = torch.rand((B, 3, 540, 960), device=dev)
 for _ in range(1):
     net.forward(x, want_heat=False, decode_size=(540, 960))
 torch.cuda.synchronize()
-net.set_profiling(True)
+net.set_profiling(os.environ.get('DEV_NOPROF', '0') != '1')
 t0 = time.time()
 for _ in range(steps):
     net.forward(x, want_heat=False, decode_size=(540, 960))

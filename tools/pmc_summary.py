@@ -7,15 +7,17 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         m = re.search(r'conv_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
-        if m: k = 'conv<k%s,s%s,NI%s,MI%s,G%s,PF%s>' % m.groups()[1:]
+        if m: k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s,PF%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
         else:
             m2 = re.search(r'conv_kernel<.*?(\d), (\d), (\d), (\d)>', k)
-            k = 'conv<NI%s,MI%s,G%s,PF%s>' % m2.groups() if m2 else k[:40]
+            k = 'conv<NI%s,MI%s,G%s,PF%s>' % m2.groups() if m2 else ('head_fused' if 'head_fused' in k else k[:48])
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         key = (r['Dispatch_Id'], k)
         if key not in seen: seen.add(key); cnt[k] += 1
 lines = []
 for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].values()))[:8]:
     lines.append('%-34s n=%4d ' % (k, cnt[k]) + ' '.join('%s=%.4g' % (n, v / cnt[k]) for n, v in sorted(c.items())))
+import json
+json.dump({k: {n: v / cnt[k] for n, v in c.items()} for k, c in acc.items()}, open(d + '/summary.json', 'w'), indent=1)
 open(d + '/summary.txt', 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))

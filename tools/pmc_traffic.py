@@ -1,0 +1,23 @@
+"""Dev helper: merge the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (tools/pmc_pass.sh) into profiles/pmc_traffic.json
+and a markdown table.  HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction of the guide)."""
+import json, sys, os
+d = sys.argv[1]; tag = sys.argv[2]; batch = sys.argv[3] if len(sys.argv) > 3 else '64'
+f = json.load(open(os.path.join(d, 'FETCH_SIZE', 'summary.json'))); w = json.load(open(os.path.join(d, 'WRITE_SIZE', 'summary.json')))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {'note': f'per-launch HBM bytes from PMC at sub-batch {batch} (profiles/{tag}_pmc_hbm_traffic.md)'}
+rows = []
+for k in f:
+    if k not in w: continue
+    fk, wk = f[k]['FETCH_SIZE'], w[k]['WRITE_SIZE']
+    out[k] = (2 * fk + wk) * 1024
+    rows.append((out[k], k, fk, wk))
+json.dump(out, open(os.path.join(root, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
+with open(os.path.join(root, 'profiles', f'{tag}_pmc_hbm_traffic.md'), 'w') as md:
+    md.write(f'# HBM traffic per launch from PMC counters ({tag})\n\n'
+             f'Two separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace -M --output-format csv -- python tools/dev_bench.py {batch} bf16 1`,\n'
+             'same with `WRITE_SIZE`; tools/pmc_pass.sh).  FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of a\n'
+             'wide coalesced read stream, so reads are doubled (MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated.\n\n'
+             '| kernel | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM MB/launch |\n|---|---|---|---|\n')
+    for b, k, fk, wk in sorted(rows, reverse=True)[:12]:
+        md.write(f'| `{k}` | {fk:.0f} | {wk:.0f} | {b / 1e6:.1f} |\n')
+print(open(os.path.join(root, 'profiles', f'{tag}_pmc_hbm_traffic.md')).read())

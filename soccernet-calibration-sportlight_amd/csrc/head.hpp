@@ -5,11 +5,17 @@
 namespace sncal {
 
 constexpr int HEAD_MAX_SRC = 5;
+constexpr int HEAD_MAX_FOLD = 2;
 
 struct HeadParams {
     const void* direct;            // [N][H][W][Cd] bf16: the tensor that already sits at head resolution
     int Cd;                        // its channel count (<= 64)
-    const void* w0;                // stage-1 A fragments [NQ][2][2][64 lanes] x 16 B (rows permuted, BN scale folded)
+    int nfold;                     // narrow branches whose upsampled channels are appended to the stage-1 K dimension
+    const void* fold[HEAD_MAX_FOLD];   // [N][Hf][Wf][Cf] bf16
+    int Cf[HEAD_MAX_FOLD], Hf[HEAD_MAX_FOLD], Wf[HEAD_MAX_FOLD];
+    float fsy[HEAD_MAX_FOLD], fsx[HEAD_MAX_FOLD];
+    int ks1;                       // stage-1 k-steps: ceil((Cd + sum Cf) / 32), rounded up to an instantiated depth
+    const void* w0;                // stage-1 A fragments [NQ][2][ks1][64 lanes] x 16 B (rows permuted, BN scale folded)
     const float* bias0;            // [HP] folded BN shift of last_layer.0 (zero on the padding)
     const void* w1;                // stage-2 A fragments [NQ][M2][64 lanes] x 16 B
     const float* bias1;            // [LC] bias of last_layer.3 (zero on the padding)

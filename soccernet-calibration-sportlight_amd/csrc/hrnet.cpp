@@ -60,6 +60,7 @@ struct Op {
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
     int group = GRP_ALL;
     int head_direct = -1, head_src[HEAD_MAX_SRC] = {-1, -1, -1, -1, -1}, head_nsrc = 0;   // OP_HEAD
+    int head_fold[HEAD_MAX_FOLD] = {-1, -1}, head_nfold = 0;                              // OP_HEAD: branches folded into stage-1 K
 };
 
 struct Tensor {
@@ -90,6 +91,7 @@ struct sncal_hrnet {
     int t_stem = -1, t_branch0 = -1;  // tensors whose dims decide whether the fused head applies
     int l_head0 = -1, l_head1 = -1;   // last_layer.0 / last_layer.3
     int head_direct_coff = 0, head_direct_c = 0, head_hp = 0, head_m2 = 0;
+    int head_k = 0, head_ks1 = 2;     // stage-1 K of the fused head (direct + folded branch channels), its k-steps
     bool fused_enabled = true, use_fused = false;
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
@@ -324,7 +326,21 @@ struct Builder {
             std::vector<int> gathered;
             if (d.upscale > 1) { hop.head_direct = t_stem; net.head_direct_coff = 0; net.head_direct_c = d.stem_width; col = d.stem_width; gathered = ys; }
             else { hop.head_direct = ys[0]; net.head_direct_coff = 0; net.head_direct_c = net.tensors[ys[0]].C; col = net.head_direct_c; gathered.assign(ys.begin() + 1, ys.end()); }
-            for (int t : gathered) {
+            // narrow branches are upsampled inside the head kernel and appended to the stage-1 K dimension (their
+            // columns of last_layer.0 follow the direct tensor's in concat order); the wide ones go through
+            // t_i = W0_i . b_i at native resolution and are gathered
+            net.head_k = net.head_direct_c;
+            size_t first = 0;
+            while (first < gathered.size() && hop.head_nfold < HEAD_MAX_FOLD && gathered.size() - first > 2 &&
+                   net.head_k + net.tensors[gathered[first]].C <= 224 && net.tensors[gathered[first]].C % 8 == 0 && net.head_k % 8 == 0) {
+                hop.head_fold[hop.head_nfold++] = gathered[first];
+                net.head_k += net.tensors[gathered[first]].C;
+                col += net.tensors[gathered[first]].C;
+                ++first;
+            }
+            net.head_ks1 = net.head_k <= 64 ? 2 : net.head_k <= 160 ? 5 : 7;
+            for (size_t gi = first; gi < gathered.size(); ++gi) {
+                const int t = gathered[gi];
                 const std::string nm = fmt("head.t%d", hop.head_nsrc);
                 const int li = add_layer(nm, "", net.tensors[t].C, net.head_hp, 1, 1, false);
                 net.layers[li].derived = true; net.layers[li].col_off = col;
@@ -431,20 +447,21 @@ int pack_head(sncal_hrnet& net) {
     const ConvLayer& H1 = net.layers[net.l_head1];
     if (!H1.is_set) { set_error("conv %s has no weights", H1.name.c_str()); return SNCAL_ERR_STATE; }
     const int HP = net.head_hp, NQ = HP / 32, M2 = net.head_m2, Cd = net.head_direct_c, coff = net.head_direct_coff;
-    if (Cd > 64 || M2 > 4) return SNCAL_OK;      // fused kernel does not apply; the reference formulation is used
-    std::vector<uint16_t> w0((size_t)NQ * 2 * 2 * 64 * 8, 0), w1((size_t)NQ * M2 * 64 * 8, 0);
+    const int K1 = net.head_k, KS1 = net.head_ks1;      // stage-1 K: the first K1 concat columns (direct + folded branches)
+    if (Cd > 64 || M2 > 4 || K1 > KS1 * 32) return SNCAL_OK;      // fused kernel does not apply; the reference formulation is used
+    std::vector<uint16_t> w0((size_t)NQ * 2 * KS1 * 64 * 8, 0), w1((size_t)NQ * M2 * 64 * 8, 0);
     std::vector<float> b0(HP, 0.f), b1((size_t)M2 * 16, 0.f);
     for (int q = 0; q < NQ; ++q)
         for (int f = 0; f < 2; ++f)
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < KS1; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int m = lane & 15, gk = lane >> 4;
                     const int ch = q * 32 + (m >> 2) * 8 + f * 4 + (m & 3);      // row permutation, see head.hip
                     if (ch >= H0.cout) continue;
-                    uint16_t* dst = w0.data() + ((((size_t)(q * 2 + f) * 2 + ks) * 64) + lane) * 8;
+                    uint16_t* dst = w0.data() + ((((size_t)(q * 2 + f) * KS1 + ks) * 64) + lane) * 8;
                     for (int e = 0; e < 8; ++e) {
                         const int k = ks * 32 + gk * 8 + e;
-                        if (k < Cd) dst[e] = f2bf(H0.w[(size_t)ch * H0.cin + coff + k] * H0.scale[ch]);
+                        if (k < K1) dst[e] = f2bf(H0.w[(size_t)ch * H0.cin + coff + k] * H0.scale[ch]);
                     }
                 }
     for (int co = 0; co < H0.cout; ++co) b0[co] = H0.shift[co];
@@ -496,6 +513,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         use(op.in); use(op.res); use(op.base); use(op.dims_from); use(op.head_direct);
         for (int s2 = 0; s2 < op.nsrc; ++s2) use(op.srcs[s2]);
         for (int s2 = 0; s2 < op.head_nsrc; ++s2) use(op.head_src[s2]);
+        for (int s2 = 0; s2 < op.head_nfold; ++s2) use(op.head_fold[s2]);
         if (op.out >= 0) { if (T[op.out].first < 0) T[op.out].first = (int)i; T[op.out].last = std::max(T[op.out].last, (int)i); }
     }
     for (const Op& op : net.ops) {
@@ -890,15 +908,23 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
                         hp.sy[s2] = to.H > 1 ? (float)(ts.H - 1) / (float)(to.H - 1) : 0.f;
                         hp.sx[s2] = to.W > 1 ? (float)(ts.W - 1) / (float)(to.W - 1) : 0.f;
                     }
+                    hp.nfold = op.head_nfold; hp.ks1 = net->head_ks1;
+                    for (int s2 = 0; s2 < op.head_nfold; ++s2) {
+                        const Tensor& tf = net->tensors[op.head_fold[s2]];
+                        hp.fold[s2] = ws + tf.offset; hp.Cf[s2] = tf.C; hp.Hf[s2] = tf.H; hp.Wf[s2] = tf.W;
+                        hp.fsy[s2] = to.H > 1 ? (float)(tf.H - 1) / (float)(to.H - 1) : 0.f;
+                        hp.fsx[s2] = to.W > 1 ? (float)(tf.W - 1) / (float)(to.W - 1) : 0.f;
+                    }
                     hp.logits = reinterpret_cast<float*>(ws + to.offset);
                     hp.N = sb; hp.H = to.H; hp.W = to.W; hp.HP = net->head_hp; hp.NQ = net->head_hp / 32; hp.LC = to.C;
                     rc = launch_head_fused(hp, net->head_m2, stream);
                     if (net->profiling) {
                         net->last_kernel = "head_fused";
                         const double px = (double)sb * to.H * to.W;
-                        net->last_flops = 2.0 * px * net->head_hp * (td.C + net->head_m2 * 16);
+                        net->last_flops = 2.0 * px * net->head_hp * (net->head_k + net->head_m2 * 16);
                         net->last_bytes = px * (td.C * 2 + to.C * 4);
                         for (int s2 = 0; s2 < op.head_nsrc; ++s2) { const Tensor& ts = net->tensors[op.head_src[s2]]; net->last_bytes += (double)sb * ts.H * ts.W * ts.C * 2; }
+                        for (int s2 = 0; s2 < op.head_nfold; ++s2) { const Tensor& tf = net->tensors[op.head_fold[s2]]; net->last_bytes += (double)sb * tf.H * tf.W * tf.C * 2; }
                     }
                     break;
                 }

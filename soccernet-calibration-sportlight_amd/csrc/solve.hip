@@ -1007,9 +1007,12 @@ __device__ void load_points(const float* kp, Pts& p) {
     p.u32 = p.u; p.v32 = p.v;
 }
 
-__global__ __launch_bounds__(64) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
-                                                       int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out) {
-    const int frame = blockIdx.x;
+// One wavefront per frame, four frames per workgroup: a solver wave owns a whole SIMD register file (512 VGPRs), so a
+// lone wave per CU would keep the co-running convolution workgroups (one wave on each SIMD) off that CU; packed, 64
+// frames block 16 CUs instead of degrading 64.  The waves of a workgroup never communicate.
+__global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
+                                                           int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out) {
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (frame >= B) return;
     const int lane = threadIdx.x & 63;
     float kp[3] = {0.f, 0.f, -1.f};
@@ -1166,7 +1169,7 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     SNCAL_CHECK_ARG(cfg->img_w > 1 && cfg->img_h > 1, "sncal_calibrate: image size");
     const int rc = ensure_pitch_uploaded();
     if (rc) return rc;
-    hipLaunchKernelGGL(calibrate_kernel, dim3(B), dim3(64), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+    hipLaunchKernelGGL(calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

@@ -388,7 +388,9 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         const double reuse = (double)(V.mi * 4) / (V.mi + 4);           // MFMAs per LDS fragment read (NI=4 nominal)
         const double per_chunk = (double)nks / (nks + 1.0);              // amortisation of the per-chunk sync/load
         // two workgroups per CU (<= 80 KB of LDS each) hide the staging rounds; judged on a nominal 2-wide tile
-        const double occ = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, 2) <= 80 * 1024 ? 1.0 : 0.55;
+        const size_t stage2 = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, 2);
+        // three resident workgroups (<= 53 KB, <= 168 VGPRs) measured 4 % faster on the latency-bound 48-channel class
+        const double occ = stage2 > 80 * 1024 ? 0.55 : (stage2 <= 53 * 1024 && conv_wgs_per_cu(V.ks, V.ni, V.mi, V.g, 0) == 3) ? 1.1 : 1.0;
         const double score = k_eff * m_eff * (0.55 + 0.45 * reuse / 2.4) * per_chunk * occ;
         if (score > best + 1e-9) { best = score; L.mi = V.mi; L.g = V.g; }
     }
@@ -596,8 +598,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
     static const int force_pf = getenv("SNCAL_FORCE_PF") ? atoi(getenv("SNCAL_FORCE_PF")) : -1;
     static const double three_gain = getenv("SNCAL_THREE_GAIN") ? atof(getenv("SNCAL_THREE_GAIN")) : 1.15;
-    static const double pf1_gain = getenv("SNCAL_PF1_GAIN") ? atof(getenv("SNCAL_PF1_GAIN")) : 1.1;
-    static const double pf2_gain = getenv("SNCAL_PF2_GAIN") ? atof(getenv("SNCAL_PF2_GAIN")) : 1.2;
+    static const double pf1_gain = getenv("SNCAL_PF1_GAIN") ? atof(getenv("SNCAL_PF1_GAIN")) : 0.9;   // the prefetch modes never measured faster than more resident workgroups
+    static const double pf2_gain = getenv("SNCAL_PF2_GAIN") ? atof(getenv("SNCAL_PF2_GAIN")) : 0.9;
     bool has_forced = false;
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];

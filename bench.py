@@ -125,17 +125,15 @@ def main():
                                  min_points_for_refinement=6, reliable_thresh=57)
     pipe = sncal_amd.CalibrationPipeline(net, cc, decode_size=(540, 960))
     last = {}
-    from sncal_amd.dist import pack_records, gather_records
 
     def step():
         # forward + decode on the main stream; both solves on the pipeline's side stream (they overlap the next
         # step's convolutions); every solve is complete before the closing fence of the timed region
-        kpts, rec_net, rec_syn = pipe.submit(x, extra_keypoints=kp_synth)
-        last['rec_syn'] = rec_syn
-        if world > 1:   # the single collective of the path: per-frame records to every rank (RCCL over xGMI)
-            pipe.join()
-            gather_records(pack_records(kpts, rec_net, rec_syn))
-        return kpts
+        # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on
+        # the side stream behind the solves
+        out = pipe.submit(x, extra_keypoints=kp_synth, gather=world > 1)
+        last['rec_syn'] = out[2]
+        return out[0]
 
     def fence():
         pipe.join()

@@ -18,9 +18,12 @@ class CalibrationPipeline:
         self.solve_stream = torch.cuda.Stream(device=self.device)
         self._pending = []
 
-    def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None):
+    def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False):
         """frames (B,3,H,W) fp32 on the GPU.  Enqueues forward+decode on the current stream and the solve(s)
-        on the side stream; returns (kpts, records[, extra_records]) device tensors (asynchronous)."""
+        on the side stream; returns (kpts, records[, extra_records][, all_ranks_records]) device tensors
+        (asynchronous).  gather=True (multi-GPU): the one collective of the path -- every rank's
+        per-frame records to every rank -- is enqueued on the SIDE stream behind the solves, so the next batch's
+        convolutions on the main stream never wait for it."""
         main = torch.cuda.current_stream(self.device)
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
         ready = torch.cuda.Event()
@@ -34,6 +37,9 @@ class CalibrationPipeline:
             out = [kpts, rec]
             if extra_keypoints is not None:
                 out.append(self.calibrator.solve_device(extra_keypoints))
+            if gather:
+                from .dist import pack_records, gather_records
+                out.append(gather_records(pack_records(*out)))
         done = torch.cuda.Event()
         done.record(self.solve_stream)
         self._pending.append(done)

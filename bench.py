@@ -89,8 +89,8 @@ def cpu_baseline(sd, cfg_name, n_frames=2, n_solve=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -677,6 +677,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     if (net.profiling) {
         net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,PF%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
                               bestv->ni, L.mi, L.g, best_pf);
+        static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
+        if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
         const double px = (double)sb * to.H * to.W;
         net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
         net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +

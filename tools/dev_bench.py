@@ -26,7 +26,7 @@ print(f'B={B} {dtype} subbatch={os.environ.get("SNCAL_SUBBATCH", "8")}: {dt*1e3:
 
 prof = sorted(net.get_profile(), key=lambda p: -p['ms'])
 tot = sum(p['ms'] for p in prof)
-for p in prof[:14]:
+for p in prof[:int(os.environ.get("DEV_TOP", "14"))]:
     tf = p['flops'] / (p['ms'] * 1e-3) / 1e12 if p['ms'] else 0
     gbs = p['bytes'] / (p['ms'] * 1e-3) / 1e9 if p['ms'] else 0
     print(f"  {p['ms']/tot*100:5.1f}%  {p['ms']/steps:8.2f} ms/step  n={p['launches']//steps:4d}  {tf:7.1f} TF  {gbs:7.0f} GB/s  {p['kernel']}")

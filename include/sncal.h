@@ -116,6 +116,14 @@ int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W,
                         float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes,
                         void* stream);
 
+/* Same forward from the frames as the reference's harness holds them BEFORE torchvision's ToTensor
+ * (make_submit.py:62-66: cv2.imread -> BGR uint8 (H,W,3) -> ToTensor = float32 x/255, CHW): d_x (B,H,W,3) uint8.
+ * Bit-identical to sncal_hrnet_forward on ToTensor's output; the input read is 3 bytes per pixel instead of 12
+ * (at thousands of frames per second the float frames are the PCIe / HBM bottleneck). */
+int sncal_hrnet_forward_u8(sncal_hrnet* net, const unsigned char* d_x, int B, int H, int W, float* d_heat,
+                           float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes,
+                           void* stream);
+
 /* Diagnostics (measurement only, no reference counterpart): per-kernel timing of forwards with HIP events
  * recorded on the caller's stream between the plan's launches.  Enable, run forwards, then read the
  * accumulated per-kernel-variant totals (the call synchronises the recorded events). */

@@ -843,13 +843,26 @@ extern "C" int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out,
     return SNCAL_OK;
 }
 
+static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char* d_x8, int B, int H, int W, float* d_heat,
+                        float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_);
+
 extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
                                    int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
+    return forward_impl(net, d_x, nullptr, B, H, W, d_heat, d_kpts, img_h, img_w, d_ws, ws_bytes, stream_);
+}
+
+extern "C" int sncal_hrnet_forward_u8(sncal_hrnet* net, const unsigned char* d_x, int B, int H, int W, float* d_heat,
+                                      float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
+    return forward_impl(net, nullptr, d_x, B, H, W, d_heat, d_kpts, img_h, img_w, d_ws, ws_bytes, stream_);
+}
+
+static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char* d_x8, int B, int H, int W, float* d_heat,
+                        float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_forward: null net");
     if (!net->finalized) { set_error("sncal_hrnet_forward: weights not finalized"); return SNCAL_ERR_STATE; }
     SNCAL_CHECK_ARG(B >= 0 && H >= 32 && W >= 32, "sncal_hrnet_forward: bad shape B=%d H=%d W=%d", B, H, W);
     if (B == 0) return SNCAL_OK;
-    SNCAL_CHECK_ARG(d_x && d_ws, "sncal_hrnet_forward: null input / workspace");
+    SNCAL_CHECK_ARG((d_x || d_x8) && d_ws, "sncal_hrnet_forward: null input / workspace");
     SNCAL_CHECK_ARG(d_heat || d_kpts, "sncal_hrnet_forward: need d_heat or d_kpts");
     SNCAL_CHECK_ARG(!(d_kpts && net->desc.head_softmax), "sncal_hrnet_forward: keypoint decode needs a log-softmax head");
     hipStream_t stream = as_stream(stream_);
@@ -870,7 +883,8 @@ extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, in
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             switch (op.type) {
                 case OP_INPUT:
-                    rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
+                    if (d_x8) rc = launch_u8hwc_to_nhwc(net->dtype, d_x8 + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, H, W, stream);
+                    else rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
                     break;
                 case OP_CONV: rc = run_conv(*net, op, sb, ws, stream); break;
                 case OP_UPADD: {

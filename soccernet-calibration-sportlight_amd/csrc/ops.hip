@@ -37,6 +37,19 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// uint8 HWC frames (what cv2.imread hands to ToTensor, make_submit.py:62-66) -> NHWC T: ToTensor's float32 x / 255,
+// then the same conversion as nchw_to_nhwc; 3 bytes per pixel read instead of 12
+template <typename T>
+__global__ __launch_bounds__(256) void u8hwc_to_nhwc_kernel(const unsigned char* __restrict__ x, T* __restrict__ y, size_t total) {
+    constexpr int GE = Vec<T>::GE;
+    for (size_t p = blockIdx.x * 256ull + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        typename Vec<T>::type v;
+#pragma unroll
+        for (int c = 0; c < GE; ++c) v[c] = (T)(c < 3 ? (float)x[p * 3 + c] / 255.0f : 0.0f);
+        *reinterpret_cast<typename Vec<T>::type*>(y + p * GE) = v;
+    }
+}
+
 // PyTorch's align_corners=True source index: scale = (in-1)/(out-1) in fp32, src = scale*dst
 struct Lerp { int i0, i1; float w0, w1; };
 __device__ __forceinline__ Lerp lerp_idx(int o, int in_size, float scale) {
@@ -157,6 +170,16 @@ int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H,
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
     else
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, N, C, H, W);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+int launch_u8hwc_to_nhwc(int dtype, const unsigned char* x, void* y, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    if (dtype == SNCAL_BF16)
+        hipLaunchKernelGGL(u8hwc_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)y, total);
+    else
+        hipLaunchKernelGGL(u8hwc_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, total);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

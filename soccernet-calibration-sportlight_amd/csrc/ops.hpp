@@ -18,6 +18,7 @@ struct UpsampleAddParams {
 };
 
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s);
+int launch_u8hwc_to_nhwc(int dtype, const unsigned char* x, void* y, int N, int H, int W, hipStream_t s);
 int launch_upsample_add(int dtype, const UpsampleAddParams& p, hipStream_t s);
 int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_total, size_t hw, int log_mode,
                         float* out, hipStream_t s);

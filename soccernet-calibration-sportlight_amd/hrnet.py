@@ -151,11 +151,17 @@ class HRNetHeatmap:
         return self._ws
 
     def forward(self, x: torch.Tensor, want_heat: bool = True, decode_size=None):
-        """x (B,3,H,W) fp32 on the GPU.  Returns (heat or None, kpts or None)."""
+        """x (B,3,H,W) fp32 in [0,1] on the GPU (ToTensor's output), or (B,H,W,3) uint8 (cv2.imread's frames, before
+        ToTensor: identical results, a quarter of the input bytes).  Returns (heat or None, kpts or None)."""
         if not self._loaded:
             raise _lib.SncalError('HRNetHeatmap: load_state_dict() has not been called')
-        _lib.require_device(x, torch.float32, 'x')
-        B, C, H, W = x.shape
+        u8 = x.dtype == torch.uint8
+        if u8:
+            _lib.require_device(x, torch.uint8, 'x')
+            B, H, W, C = x.shape
+        else:
+            _lib.require_device(x, torch.float32, 'x')
+            B, C, H, W = x.shape
         if C != 3:
             raise _lib.SncalError('x must have 3 channels')
         h, w = self.output_size(H, W)
@@ -167,10 +173,11 @@ class HRNetHeatmap:
             kpts = torch.empty((B, self.num_classes - 1, 3), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             ws = self._workspace(B, H, W)
-            _lib.check(self._L.sncal_hrnet_forward(self._h, x.data_ptr(), B, H, W,
-                                                   heat.data_ptr() if heat is not None else None,
-                                                   kpts.data_ptr() if kpts is not None else None, ih, iw,
-                                                   ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
+            fn = self._L.sncal_hrnet_forward_u8 if u8 else self._L.sncal_hrnet_forward
+            _lib.check(fn(self._h, x.data_ptr(), B, H, W,
+                          heat.data_ptr() if heat is not None else None,
+                          kpts.data_ptr() if kpts is not None else None, ih, iw,
+                          ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
                        'sncal_hrnet_forward')
         return heat, kpts
 

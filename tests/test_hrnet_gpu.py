@@ -110,3 +110,18 @@ def test_load_model_predict_surface(sncal, cuda, tmp_path):
     ref = od.keypoint_decode(hr.forward(sd, x, cfg).numpy(), (540, 960))
     assert np.array_equal(pred.cpu().numpy()[..., :2], ref[..., :2])
     assert np.array_equal(model.nn_module(x.to(cuda))[-1].shape, (2, 58, 68, 120))
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_uint8_frames_equal_totensor_frames(sncal, cuda, dtype):
+    """sncal_hrnet_forward_u8 on cv2-style (B,H,W,3) uint8 frames == sncal_hrnet_forward on torchvision ToTensor's
+    output of the same frames (make_submit.py:62-66: permute to CHW, float32, divide by 255): bit-identical."""
+    cfg = hr.load_config('hrnet_w18')
+    net = sncal.HRNetHeatmap('hrnet_w18', dtype=dtype, device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 3, 4.0))
+    gen = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (3, 64, 96, 3), dtype=torch.uint8, generator=gen)
+    as_totensor = frames.permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)
+    h8, k8 = net.forward(frames.to(cuda), want_heat=True, decode_size=(540, 960))
+    hf, kf = net.forward(as_totensor.to(cuda), want_heat=True, decode_size=(540, 960))
+    assert torch.equal(h8, hf) and torch.equal(k8, kf)

@@ -1,0 +1,21 @@
+// Parameters / launcher of the fused 48-channel BasicBlock kernel (bblock.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sncal {
+
+struct BBlockParams {
+    const void* x;          // [N][H][W][48] bf16 block input (also the residual)
+    void* out;              // [N][H][W][48] bf16
+    const void* w1;         // conv1 weights, generic conv packing for (MI = 3, G = 3): [2 chunks][7 k-steps][3][64 lanes] x 16 B
+    const void* w2;         // conv2 weights, same packing
+    const float* b1;        // folded-BN shifts (48 floats each)
+    const float* b2;
+    int N, H, W;
+    int tiles_x, tiles_y;   // filled by the launcher
+    unsigned long long* trace;   // tuning aid (SNCAL_BB_TRACE=<file>): 16 s_memtime stamps per workgroup, or null
+};
+
+int launch_bblock48(const BBlockParams& p, hipStream_t s);
+
+}  // namespace sncal

@@ -17,6 +17,7 @@
 #include "conv.hpp"
 #include "ops.hpp"
 #include "head.hpp"
+#include "bblock.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -93,6 +94,7 @@ struct sncal_hrnet {
     int head_direct_coff = 0, head_direct_c = 0, head_hp = 0, head_m2 = 0;
     int head_k = 0, head_ks1 = 2;     // stage-1 K of the fused head (direct + folded branch channels), its k-steps
     bool fused_enabled = true, use_fused = false;
+    bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
     int cur_group = GRP_ALL;
@@ -878,15 +880,51 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
         hipEvent_t prev = nullptr;
         if (net->profiling) { prev = next_event(*net); if (prev) SNCAL_CHECK_HIP(hipEventRecord(prev, stream)); }
-        for (const Op& op : net->ops) {
+        bool skip_next = false;
+        for (size_t oi = 0; oi < net->ops.size(); ++oi) {
+            const Op& op = net->ops[oi];
             if (!op_active(*net, op)) continue;
+            if (skip_next) { skip_next = false; continue; }      // second conv of a fused BasicBlock
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             switch (op.type) {
                 case OP_INPUT:
                     if (d_x8) rc = launch_u8hwc_to_nhwc(net->dtype, d_x8 + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, H, W, stream);
                     else rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
                     break;
-                case OP_CONV: rc = run_conv(*net, op, sb, ws, stream); break;
+                case OP_CONV: {
+                    // BasicBlock of the 48-channel branch: conv1 + conv2 (+ residual) fused when the next active op
+                    // is its second convolution and both layers carry the (MI = 3, G = 3) packing
+                    const Op* op2 = nullptr;
+                    if (net->fuse_bblock && net->dtype == SNCAL_BF16 && op.relu && op.res < 0 && !op.out_f32 && oi + 1 < net->ops.size()) {
+                        const Op& nx = net->ops[oi + 1];
+                        if (nx.type == OP_CONV && op_active(*net, nx) && nx.in == op.out && nx.res == op.in && nx.relu && !nx.out_f32 &&
+                            nx.out_coff == 0 && op.out_coff == 0) {
+                            const ConvLayer& A = net->layers[op.conv]; const ConvLayer& Bl = net->layers[nx.conv];
+                            auto ok = [&](const ConvLayer& L) { return L.k == 3 && L.stride == 1 && L.cin == 48 && L.cout == 48 && L.cin_phys == 48 &&
+                                                                       L.mi == 3 && L.g == 3 && L.chunks == 2 && L.nblk == 1; };
+                            if (ok(A) && ok(Bl) && net->tensors[op.in].C == 48 && net->tensors[nx.out].C == 48) op2 = &nx;
+                        }
+                    }
+                    if (op2) {
+                        const Tensor& ti = net->tensors[op.in];
+                        BBlockParams bp;
+                        bp.x = ws + ti.offset; bp.out = ws + net->tensors[op2->out].offset;
+                        bp.w1 = net->layers[op.conv].d_w; bp.b1 = net->layers[op.conv].d_bias;
+                        bp.w2 = net->layers[op2->conv].d_w; bp.b2 = net->layers[op2->conv].d_bias;
+                        bp.N = sb; bp.H = ti.H; bp.W = ti.W; bp.tiles_x = bp.tiles_y = 0; bp.trace = nullptr;
+                        rc = launch_bblock48(bp, stream);
+                        if (net->profiling) {
+                            net->last_kernel = "bblock48_fused";
+                            const double px = (double)sb * ti.H * ti.W;
+                            net->last_flops = 2.0 * 2.0 * px * 48 * 48 * 9;
+                            net->last_bytes = 2.0 * px * 48 * 2 + 2.0 * 48 * 48 * 9 * 2;
+                        }
+                        skip_next = true;
+                    } else {
+                        rc = run_conv(*net, op, sb, ws, stream);
+                    }
+                    break;
+                }
                 case OP_UPADD: {
                     const Tensor& to = net->tensors[op.out];
                     UpsampleAddParams p;

@@ -125,3 +125,23 @@ def test_uint8_frames_equal_totensor_frames(sncal, cuda, dtype):
     h8, k8 = net.forward(frames.to(cuda), want_heat=True, decode_size=(540, 960))
     hf, kf = net.forward(as_totensor.to(cuda), want_heat=True, decode_size=(540, 960))
     assert torch.equal(h8, hf) and torch.equal(k8, kf)
+
+
+def test_fused_basicblock_is_bit_identical_to_two_convs(sncal, cuda, monkeypatch):
+    """bblock.hip (conv1+BN+ReLU+conv2+BN+residual+ReLU of the 48-channel branch in one kernel) keeps the MFMA
+    order and the bf16 rounding of the intermediate, so the whole bf16 network output must not change by one bit
+    (odd sizes: tiles are 12x14, the image is 135x240 at the branch)."""
+    cfg = hr.load_config('hrnet_w48')
+    sd = hr.seeded_state_dict(cfg, 2, 1.5)
+    x = hr.seeded_input(2, 540, 960, 9).to(cuda)
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SNCAL_FUSE_BBLOCK', flag)
+        net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+        net.load_state_dict(sd)
+        net.set_profiling(True)
+        heat, _ = net.forward(x, want_heat=True)
+        kernels = {p['kernel'] for p in net.get_profile()}
+        assert ('bblock48_fused' in kernels) == (flag == '1')
+        outs.append(heat.clone())
+    assert torch.equal(outs[0], outs[1])

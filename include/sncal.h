@@ -64,6 +64,18 @@ int sncal_line_decode(const float* d_heat, int B, int C, int h, int w, float sig
                       float* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * L3 + L4  line peaks -> line equations -> the 30 intersection keypoint candidates
+ * replaces get_line_data / calculate_slope_intercept  src/utils/export_line_result.py:51-131,
+ *          CameraCreator.__init__ lines ingestion     src/models/hrnet/prediction.py:105-124,
+ *          line_eq_intersection                       src/models/hrnet/prediction.py:643-653
+ *   d_peaks (B,23,2,3) fp32 rows [x, y, p] in heatmap units (sncal_line_decode with scale 1; LINE_CLS order);
+ *   d_out   (B,30,3) fp32 rows [x, y, valid] = sncal_calibrate's d_line_pts (ids of LINE_INTERSECTIONS).
+ * Arithmetic as in the reference's pinned numpy 1.24.2: float32 coordinates, float64 from `+ 1e-5` on.
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_lines_to_points(const float* d_peaks, int B, float scale, double prob_thre, float* d_out,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * M1-M5, L1  HRNet keypoint / line network
  * replaces HighResolutionNet.__init__/forward  src/models/hrnet/hrnet.py:255-355, 437-511,
  *          src/models/line/hrnet.py:30-249, HRNetHeatmap.forward src/models/hrnet/model.py:143-150

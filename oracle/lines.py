@@ -39,11 +39,16 @@ LINE_INTERSECTIONS: Dict[int, Tuple[str, str]] = {
 
 
 def slope_intercept(p1, p2, delta: float = 0.00001):
-    """export_line_result.py:51-82."""
+    """export_line_result.py:51-82 with the scalar promotion of the reference's pinned numpy 1.24.2: float32
+    coordinates stay float32 through the differences, `+ delta` (a python float) promotes to float64."""
     if tuple(p1) == tuple(p2):
         return None, None
     x1, y1 = p1
     x2, y2 = p2
+    if isinstance(x1, np.float32):
+        dy, dx = np.float32(y2) - np.float32(y1), np.float32(x2) - np.float32(x1)
+        slope = float(dy) / (float(dx) + delta)
+        return slope, float(y1) - slope * float(x1)
     slope = (y2 - y1) / (x2 - x1 + delta)
     return slope, y1 - slope * x1
 
@@ -86,3 +91,16 @@ def lines_to_keypoints(pred: Dict[str, Tuple[float, float]]) -> Dict[int, Tuple[
             if ip is not None:
                 pts[idx] = ip
     return pts
+
+
+def keypoints_array(peaks: np.ndarray, scale=4, prob_thre: float = 0.2) -> np.ndarray:
+    """L3 + L4 for a batch: peaks (B,23,2,3) float32 -> (B,30,3) float32 rows [x, y, valid] (the d_line_pts of the
+    solver).  A (None, None) line (two identical peaks; the reference would raise on it at prediction.py:650) counts
+    as missing."""
+    out = np.zeros((peaks.shape[0], 30, 3), dtype=np.float32)
+    for b in range(peaks.shape[0]):
+        lines, _ = get_line_data(peaks[b:b + 1], scale=np.float32(scale) if isinstance(scale, float) else scale, prob_thre=prob_thre)
+        lines = {k: v for k, v in lines.items() if v[0] is not None}
+        for i, (x, y) in lines_to_keypoints(lines).items():
+            out[b, i] = (x, y, 1.0)
+    return out

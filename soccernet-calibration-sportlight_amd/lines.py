@@ -40,10 +40,16 @@ LINE_INTERSECTIONS.update({
 
 
 def calculate_slope_intercept(point1, point2, delta: float = 0.00001):
+    """float32 numpy coordinates follow the reference's pinned numpy 1.24.2 promotion (differences in float32,
+    float64 from `+ delta` on) whatever numpy is installed; python floats are plain float64 arithmetic."""
     if tuple(point1) == tuple(point2):
         return None, None
     x1, y1 = point1
     x2, y2 = point2
+    if isinstance(x1, np.float32):
+        dy, dx = np.float32(y2) - np.float32(y1), np.float32(x2) - np.float32(x1)
+        slope = float(dy) / (float(dx) + delta)
+        return slope, float(y1) - slope * float(x1)
     slope = (y2 - y1) / (x2 - x1 + delta)
     return slope, y1 - slope * x1
 
@@ -95,3 +101,18 @@ def keypoints_to_array(points: Dict[int, Tuple[float, float]]) -> np.ndarray:
     for i, (x, y) in points.items():
         a[i] = (x, y, 1.0)
     return a
+
+
+def lines_to_points_device(peaks, scale: float = 4.0, prob_thre: float = 0.2):
+    """L3 + L4 on the GPU for a batch: peaks (B,23,2,3) float32 cuda tensor (line decode in heatmap units) ->
+    (B,30,3) float32 cuda tensor [x, y, valid], the `d_line_pts` argument of CameraCreator.solve_device."""
+    import torch
+    from . import _lib
+    _lib.require_device(peaks, torch.float32, 'peaks')
+    if tuple(peaks.shape[1:]) != (23, 2, 3):
+        raise _lib.SncalError('peaks must be (B,23,2,3)')
+    out = torch.empty((peaks.shape[0], 30, 3), dtype=torch.float32, device=peaks.device)
+    with torch.cuda.device(peaks.device):
+        _lib.check(_lib.lib().sncal_lines_to_points(peaks.data_ptr(), peaks.shape[0], float(scale), float(prob_thre),
+                                                    out.data_ptr(), _lib.current_stream_ptr()), 'sncal_lines_to_points')
+    return out

@@ -10,10 +10,18 @@ from . import _lib
 
 
 class CalibrationPipeline:
-    def __init__(self, net, calibrator, decode_size=(540, 960)):
+    def __init__(self, net, calibrator, decode_size=(540, 960), line_net=None, line_sigma=3.0, line_scale=4,
+                 line_prob_thre=0.0):
+        """line_net (optional, BASELINE config C4): the line model runs on the same frames; its two-peak decode
+        (EHMPredictionTransform.mask_heat_points_gauss, sigma as export_line_result.py:147-149), the line equations
+        and the 30 line-intersection keypoints (export_line_result.py:51-131 with its CLI defaults scale 4,
+        prob_thre 0; prediction.py:105-124) stay on the device and feed the solver directly -- the reference goes
+        through a pickle file between two scripts."""
         self.net = net
         self.calibrator = calibrator
         self.decode_size = decode_size
+        self.line_net = line_net
+        self.line_sigma, self.line_scale, self.line_prob_thre = float(line_sigma), float(line_scale), float(line_prob_thre)
         self.device = net.device
         self.solve_stream = torch.cuda.Stream(device=self.device)
         self._pending = []
@@ -28,11 +36,21 @@ class CalibrationPipeline:
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
         ready = torch.cuda.Event()
         ready.record(main)
-        lp = self.calibrator.line_points_array(names)
-        d_lp = torch.from_numpy(lp).to(self.device, non_blocking=True) if lp is not None else None
+        if self.line_net is not None:
+            from .lines import lines_to_points_device
+            from .transforms import EHMPredictionTransform
+            heat_l, _ = self.line_net.forward(frames, want_heat=True)
+            peaks = EHMPredictionTransform.mask_heat_points_gauss(heat_l, sigma=self.line_sigma)
+            d_lp = lines_to_points_device(peaks, scale=self.line_scale, prob_thre=self.line_prob_thre)
+            ready.record(main)           # the solve also waits for the line branch
+        else:
+            lp = self.calibrator.line_points_array(names)
+            d_lp = torch.from_numpy(lp).to(self.device, non_blocking=True) if lp is not None else None
         with torch.cuda.stream(self.solve_stream):
             self.solve_stream.wait_event(ready)
             kpts.record_stream(self.solve_stream)
+            if d_lp is not None:
+                d_lp.record_stream(self.solve_stream)
             rec = self.calibrator.solve_device(kpts, d_lp)
             out = [kpts, rec]
             if extra_keypoints is not None:

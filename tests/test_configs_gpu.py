@@ -61,6 +61,22 @@ def test_c4_keypoint_and_line_networks_joined(sncal, cuda):
         assert np.allclose(km[k], ko[k], rtol=1e-4, atol=1e-3)
     arr = sncal.lines.keypoints_to_array(km)
     assert arr.shape == (30, 3) and arr[:, 2].sum() == len(km)
+    # the same chain on the device (sncal_lines_to_points): bit-identical to the host mirror's array
+    dev = sncal.lines.lines_to_points_device(dec, scale=4, prob_thre=0.0).cpu().numpy()
+    assert np.array_equal(dev[0].view(np.uint32), arr.view(np.uint32))
+    # ... and inside the pipeline: keypoint net + line net on the same frames, line candidates straight into the solve
+    cfgk = hr.load_config('hrnet_w18')
+    knet = sncal.HRNetHeatmap('hrnet_w18', dtype='fp32', device=cuda)
+    knet.load_state_dict(hr.seeded_state_dict(cfgk, 6, 4.0))
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter',
+                             max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0,
+                             min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
+    kps = torch.from_numpy(np.stack([synth.synth_keypoints(720)[0]])).to(cuda)
+    pipe = sncal.CalibrationPipeline(knet, cc, line_net=lnet)
+    out = pipe.submit(x.to(cuda), extra_keypoints=kps)
+    cams = pipe.cameras(out[1])
+    direct = cc.records(cc.solve_device(out[0], torch.from_numpy(dev).to(cuda)))
+    assert len(cams) == 1 and (cams[0] is None) == (direct[0].status == 0)
 
 
 def test_c5_1080p_shapes(sncal, cuda):

@@ -86,3 +86,30 @@ def test_line_decode_full_size_vs_oracle(sncal, cuda):
     assert np.array_equal(out, od.line_decode(heat, 3.0, 4.0))
     raw = sncal.EHMPredictionTransform.mask_heat_points_gauss(torch.from_numpy(heat).to(cuda), sigma=3).cpu().numpy()
     assert np.array_equal(raw, od.line_decode(heat, 3.0, 1.0))
+
+
+def test_lines_to_points_matches_oracle_bit_exact(sncal, cuda, gold_dir):
+    """sncal_lines_to_points (L3 + L4 on the device) vs oracle.lines.keypoints_array: float32 outputs bit-identical
+    (both run the float64 arithmetic of the reference's pinned numpy on float32 peaks)."""
+    from oracle import lines as ol
+    from sncal_amd.lines import lines_to_points_device
+    rng = np.random.default_rng(11)
+    B = 96
+    peaks = np.zeros((B, 23, 2, 3), dtype=np.float32)
+    peaks[..., 0] = rng.integers(0, 240, size=(B, 23, 2))
+    peaks[..., 1] = rng.integers(0, 135, size=(B, 23, 2))
+    peaks[..., 2] = rng.uniform(0.0, 1.0, size=(B, 23, 2))
+    peaks[0, :, :, 2] = 0.2                       # p == threshold counts (>=)
+    peaks[1, :, 1] = peaks[1, :, 0]               # identical peaks -> the reference's (None, None) line -> no line
+    peaks[2, :, :, 1] = 50.0                      # all lines horizontal: |k1 - k2| <= 1e-4 -> no intersections
+    peaks[3, :, 1, 0] = peaks[3, :, 0, 0]         # vertical lines: slope through the 1e-5 delta
+    peaks[3, :, 1, 1] = peaks[3, :, 0, 1] + 7
+    g = np.load(os.path.join(gold_dir, 'decode_lines.npz'))
+    peaks[4] = g['out_sigma3'][0] / np.array([4, 4, 1], dtype=np.float32)      # the reference-captured decode
+    ref = ol.keypoints_array(peaks, scale=4, prob_thre=0.2)
+    got = lines_to_points_device(torch.from_numpy(peaks).to(cuda), scale=4.0, prob_thre=0.2).cpu().numpy()
+    assert np.array_equal(got[..., 2], ref[..., 2])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert ref[2, :, 2].sum() == 0 and ref[1, :, 2].sum() == 0 and ref[4, :, 2].sum() >= 10
+    empty = lines_to_points_device(torch.zeros((0, 23, 2, 3), device=cuda))
+    assert empty.shape == (0, 30, 3)

@@ -219,11 +219,15 @@ def gen_lines():
     import tempfile
     g = np.load(os.path.join(GOLD, 'decode_lines.npz'))
     hl = g['out_sigma3'][:1] / np.array([4, 4, 1], dtype=np.float32)   # back to heatmap units
-    lines, points = get_line_data(hl, scale=4, prob_thre=0.2)
+    # The reference pins numpy 1.24.2, whose scalar promotion turns `x2 - x1 + delta` into float64; numpy 2 (installed
+    # here) would keep float32.  Peak coordinates are integers, so feeding the reference float64 copies reproduces
+    # the pinned arithmetic exactly (every float32 step before the promotion is exact); the oracle gets the float32
+    # array and must agree to the last bit.
+    lines, points = get_line_data(hl.astype(np.float64), scale=4, prob_thre=0.2)
     ml, mp = ol.get_line_data(hl, scale=4, prob_thre=0.2)
     assert lines.keys() == ml.keys()
     for k in lines:
-        assert np.allclose(lines[k], ml[k])
+        assert tuple(float(v) for v in lines[k]) == tuple(float(v) for v in ml[k]), (k, lines[k], ml[k])
     assert calculate_slope_intercept((1., 2.), (1., 2.)) == ol.slope_intercept((1., 2.), (1., 2.)) == (None, None)
     # ingestion through CameraCreator.__init__ (prediction.py:105-124)
     pk = {'img_a.jpg': {'lines': [dict(lines)], 'points': [points]}}

@@ -34,12 +34,10 @@
 // What bounds the kernel (per-workgroup s_memtime traces, profiles/): a staging round is LATENCY-bound -- weights
 // are L2 hits (~58 B/clk/CU), the halo comes from HBM/Infinity Cache (2-3k clk under load) -- and a workgroup
 // that issues a round and then waits leaves the CU without MFMA work ~50 % of the time even with a second
-// resident workgroup.  PF selects how much of the next chunk is in flight under the current chunk's MFMAs:
-//   PF = 0  single buffers: issue chunk c, wait, multiply (single-chunk layers; big tiles)
-//   PF = 1  halo double-buffered: the HBM part of chunk c+1 is prefetched, the weight chunk (L2) is not
-//   PF = 2  halo and weights double-buffered: the whole of chunk c+1 is prefetched
-// with LDS = (PF == 2 ? 2 : 1) * weights + (PF >= 1 ? 2 : 1) * halo; the host picks (variant, tile, PF) per layer
-// so that two or three workgroups stay resident per CU.
+// resident workgroup.  Explicit prefetch of the next chunk (halo only, or halo + weights, double-buffered in LDS)
+// was built and measured: the waits disappear but the DMA issue cost (~100 clk per 1 KB piece on the issuing wave)
+// moves into the MFMA phase and the doubled LDS footprint costs a resident workgroup -- never faster than single
+// buffers with two or three workgroups per CU, so the kernel keeps single buffers only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -109,16 +107,16 @@ __host__ __device__ constexpr int conv_max_halo_pieces(int KS, int S, int NI, in
 // a staging round is latency-bound (~3k clk), more workgroups in flight hide it.  (A fifth, DMA-only producer
 // wave per workgroup was tried: two 5-wave workgroups only co-reside on a CU at <= 128 VGPRs -- wave placement
 // starts at the same SIMD -- which this register tile cannot meet.)
-__host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G, int PF) {
-    return (conv_nks(KS, G) * MI * (PF == 2 ? 2 : 1) <= 32 && MI * NI <= 18) ? 3 : 2;
+__host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G) {
+    return (conv_nks(KS, G) * MI <= 32 && MI * NI <= 18) ? 3 : 2;
 }
 
 // workgroups per CU / epilogue staging depth of a variant (host and device agree through these)
-__host__ __device__ constexpr int conv_resident_wgs(int KS, int NI, int MI, int G, int PF) {
-    return conv_wgs_per_cu(KS, NI, MI, G, PF);
+__host__ __device__ constexpr int conv_resident_wgs(int KS, int NI, int MI, int G) {
+    return conv_wgs_per_cu(KS, NI, MI, G);
 }
-__host__ __device__ constexpr int conv_epi_frags(int KS, int NI, int MI, int G, int PF) {
-    return epi_frags(NI, conv_resident_wgs(KS, NI, MI, G, PF));
+__host__ __device__ constexpr int conv_epi_frags(int KS, int NI, int MI, int G) {
+    return epi_frags(NI, conv_resident_wgs(KS, NI, MI, G));
 }
 
 inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
@@ -131,8 +129,8 @@ inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int PF>
-__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_kernel(const ConvParams p) {
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kernel(const ConvParams p) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
     constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
@@ -183,9 +181,9 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const int n_halo_instr = halo_bytes / 1024;
 
-    // LDS: [weights 0][weights 1 if PF == 2][halo 0][halo 1 if PF >= 1]
+    // LDS: [weight chunk][halo tile]
     constexpr int W_BYTES = NKS * MI * 1024;
-    char* const s_halo0 = smem + (PF == 2 ? 2 : 1) * W_BYTES;
+    char* const s_halo0 = smem + W_BYTES;
     auto issue_weights = [&](int c, int buf) {   // lane-linear 1 KB pieces, round-robin over the issuing waves
         if (p.ablate & 6) return;
         const unsigned wbase = (unsigned)(((size_t)nb * p.cin_chunks + c) * W_BYTES);
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
     // known up front, so the residual is requested now and arrives under the main loop
     constexpr int EPI_CO = MI * 16, EPI_GROUPS = EPI_CO / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;
-    constexpr bool RES_PF = MI * NI <= 24 && conv_wgs_per_cu(KS, NI, MI, G, PF) == 2;   // big accumulator sets leave no registers for the prefetch
+    constexpr bool RES_PF = MI * NI <= 24 && conv_wgs_per_cu(KS, NI, MI, G) == 2;   // big accumulator sets leave no registers for the prefetch
     bf16x8 res_pf[RES_PF ? NI : 1][EPI_ITERS];
     const bool epi_a = GE == 8 && p.epi_lds && !p.out_f32;
     if constexpr (GE == 8 && RES_PF) {
@@ -282,7 +280,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
     }
 
     for (int c = 0; c < p.cin_chunks; ++c) {
-        if (PF == 0 && c > 0) {
+        if (c > 0) {
             asm volatile("s_barrier" ::: "memory");                       // everyone finished reading the buffers
             issue_weights(c, 0); issue_halo(c, 0);
             if (c == 1) stamp(12);
@@ -291,12 +289,8 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
         if (c == 1) stamp(13);
         asm volatile("s_barrier" ::: "memory");                           // ... everyone's; the MFMAs of chunk c-1 are over
         stamp(2 + 2 * c);
-        if (PF > 0 && c + 1 < p.cin_chunks) {                             // lands under the MFMAs of chunk c
-            issue_halo(c + 1, (c + 1) & 1);
-            if (PF == 2) issue_weights(c + 1, (c + 1) & 1);
-        }
-        const char* const s_w = smem + (PF == 2 ? (c & 1) * W_BYTES : 0);
-        const char* const s_in = s_halo0 + (PF > 0 ? (c & 1) * halo_bytes : 0);
+        const char* const s_w = smem;
+        const char* const s_in = s_halo0;
         // fragment offsets of k-step s (compile-time tap arithmetic when the 4 k-groups of a step share a tap)
         auto frag_off = [&](int s) -> int {
             if constexpr (G % 4 == 0) {
@@ -349,10 +343,6 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
         }
         }
         stamp(3 + 2 * c);
-        if (PF == 1 && c + 1 < p.cin_chunks) {                            // single weight buffer: refill once everyone is done with it
-            asm volatile("s_barrier" ::: "memory");
-            issue_weights(c + 1, 0);
-        }
     }
 
     // ---- epilogue A (bf16 outputs): transpose through LDS (the staging
@@ -364,7 +354,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G, PF)) void conv_
             constexpr int CO = MI * 16, PITCH = CO + 4;                   // floats per staged pixel row
             asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
             stamp(10);
-            constexpr int JB = conv_epi_frags(KS, NI, MI, G, PF);                              // fragments staged at a time
+            constexpr int JB = conv_epi_frags(KS, NI, MI, G);                              // fragments staged at a time
             float* stg = reinterpret_cast<float*>(smem) + wave * (JB * 16 * PITCH);
             constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS, EITERS = (ITEMS + 63) / 64;
             const size_t img_out = (size_t)n * p.Hout * p.Wout * p.out_cstride;
@@ -479,18 +469,18 @@ typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
-    ConvLaunchFn launch[3];          // PF = 0, 1, 2 (prefetch depth, see the header)
+    ConvLaunchFn launch;
 };
 
-template <typename T, int KS, int STRIDE, int NI, int MI, int G, int PF>
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
 void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KB dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G, PF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, NI, MI, G>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G, PF>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

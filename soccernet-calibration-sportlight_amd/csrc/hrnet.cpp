@@ -392,7 +392,7 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         // two workgroups per CU (<= 80 KB of LDS each) hide the staging rounds; judged on a nominal 2-wide tile
         const size_t stage2 = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, 2);
         // three resident workgroups (<= 53 KB, <= 168 VGPRs) measured 4 % faster on the latency-bound 48-channel class
-        const double occ = stage2 > 80 * 1024 ? 0.55 : (stage2 <= 53 * 1024 && conv_wgs_per_cu(V.ks, V.ni, V.mi, V.g, 0) == 3) ? 1.1 : 1.0;
+        const double occ = stage2 > 80 * 1024 ? 0.55 : (stage2 <= 53 * 1024 && conv_wgs_per_cu(V.ks, V.ni, V.mi, V.g) == 3) ? 1.1 : 1.0;
         const double score = k_eff * m_eff * (0.55 + 0.45 * reuse / 2.4) * per_chunk * occ;
         if (score > best + 1e-9) { best = score; L.mi = V.mi; L.g = V.g; }
     }
@@ -596,18 +596,14 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
     // pick NI / tile shape / sub-tiles per weight chunk for this spatial size
     const ConvVariant* bestv = nullptr;
-    int best_twf = 1, best_pf = 0; double best_score = -1; size_t best_lds = 0;
+    int best_twf = 1; double best_score = -1; size_t best_lds = 0;
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
-    static const int force_pf = getenv("SNCAL_FORCE_PF") ? atoi(getenv("SNCAL_FORCE_PF")) : -1;
     static const double three_gain = getenv("SNCAL_THREE_GAIN") ? atof(getenv("SNCAL_THREE_GAIN")) : 1.15;
-    static const double pf1_gain = getenv("SNCAL_PF1_GAIN") ? atof(getenv("SNCAL_PF1_GAIN")) : 0.9;   // the prefetch modes never measured faster than more resident workgroups
-    static const double pf2_gain = getenv("SNCAL_PF2_GAIN") ? atof(getenv("SNCAL_PF2_GAIN")) : 0.9;
     bool has_forced = false;
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks == L.k && V.stride == L.stride && V.mi == L.mi && V.g == L.g && V.ni == force_ni) has_forced = true;
     }
-    for (int pass = 0; pass < 2 && !bestv; ++pass)          // pass 1: the tuning knobs excluded everything -> ignore them
     for (int v = 0; v < net.nvariants; ++v) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride || V.mi != L.mi || V.g != L.g) continue;
@@ -619,22 +615,16 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
             const int th = F / twf;
             const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
             if (lds > 160 * 1024 || lds - wchunk > 64 * 1024) continue;   // halo tiles are capped at 64 DMA pieces
-            for (int pf = 0; pf < 3; ++pf) {                                      // prefetch depth (conv.hpp header)
-                if (pass == 0 && force_pf >= 0 && pf != force_pf && L.chunks > 1) continue;
-                if (pf > 0 && L.chunks < 2) continue;
-                const size_t lds_t = wchunk * (pf == 2 ? 2 : 1) + (lds - wchunk) * (pf >= 1 ? 2 : 1);
-                if (lds_t > 160 * 1024) continue;
-                const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
-                const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
-                const long blocks = ty * tx * sb * L.nblk;
-                const int per_cu = (int)std::min<size_t>(conv_resident_wgs(V.ks, V.ni, V.mi, V.g, pf), (160 * 1024) / lds_t);
-                const double fill = std::min(1.0, (double)blocks / (256.0 * per_cu));
-                const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
-                // exposed staging latency: hidden by co-resident workgroups and by the prefetch depth
-                const double overlap = (per_cu >= 3 ? three_gain : per_cu >= 2 ? 1.0 : 0.55) * (pf == 0 ? 1.0 : pf == 1 ? pf1_gain : pf2_gain);
-                const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap;
-                if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds_t; best_pf = pf; }
-            }
+            const long ty = (to.H + th - 1) / th, tx = (to.W + 16 * twf - 1) / (16 * twf);
+            const double eff = (double)to.H * to.W / ((double)ty * th * tx * 16 * twf);
+            const long blocks = ty * tx * sb * L.nblk;
+            const int per_cu = (int)std::min<size_t>(conv_resident_wgs(V.ks, V.ni, V.mi, V.g), (160 * 1024) / lds);
+            const double fill = std::min(1.0, (double)blocks / (256.0 * per_cu));
+            const double reuse = (double)(V.mi * V.ni) / (V.mi + V.ni);       // MFMAs per LDS fragment read
+            // exposed staging latency is hidden by co-resident workgroups only (see conv.hpp)
+            const double overlap = per_cu >= 3 ? three_gain : per_cu >= 2 ? 1.0 : 0.55;
+            const double score = eff * (0.3 + 0.7 * fill) * std::pow(reuse, 0.6) * overlap;
+            if (score > best_score + 1e-9) { best_score = score; bestv = &V; best_twf = twf; best_lds = lds; }
         }
     }
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
@@ -646,8 +636,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     {   // LDS-transposed epilogue: the fp32 tile of the 4 waves is staged in the (grown, if that keeps two
         // workgroups per CU) dynamic LDS; needs whole 8-channel groups
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
-        const int wgs = conv_resident_wgs(L.k, bestv->ni, L.mi, L.g, best_pf);
-        const size_t need = (size_t)4 * conv_epi_frags(L.k, bestv->ni, L.mi, L.g, best_pf) * 16 * (L.mi * 16 + 4) * 4;
+        const int wgs = conv_resident_wgs(L.k, bestv->ni, L.mi, L.g);
+        const size_t need = (size_t)4 * conv_epi_frags(L.k, bestv->ni, L.mi, L.g) * 16 * (L.mi * 16 + 4) * 4;
         const bool shape_ok = net.dtype == SNCAL_BF16 && !op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0;
         const size_t now_per_cu = std::min<size_t>(wgs, (160 * 1024) / best_lds);
         const bool fits = need <= best_lds || need <= (160 * 1024) / now_per_cu || need <= 52 * 1024;
@@ -658,8 +648,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.w_bytes = (unsigned)((size_t)L.nblk * L.chunks * conv_nks(L.k, L.g) * L.mi * 1024);
     { static const int extra = getenv("SNCAL_EXTRA_LDS") ? atoi(getenv("SNCAL_EXTRA_LDS")) : 0; best_lds = std::min<size_t>(best_lds + extra, 160 * 1024); }
     { static const bool dbg = getenv("SNCAL_CONV_DEBUG") != nullptr;
-      if (dbg) fprintf(stderr, "[conv] %-44s %dx%d cin %d cout %d: NI%d MI%d G%d PF%d twf %d lds %zu grid %dx%d epi_lds %d\n", L.name.c_str(), to.H, to.W, L.cin, L.cout,
-                       bestv->ni, L.mi, L.g, best_pf, best_twf, best_lds, p.tiles_x * p.tiles_y * sb, L.nblk, p.epi_lds); }
+      if (dbg) fprintf(stderr, "[conv] %-44s %dx%d cin %d cout %d: NI%d MI%d G%d twf %d lds %zu grid %dx%d epi_lds %d\n", L.name.c_str(), to.H, to.W, L.cin, L.cout,
+                       bestv->ni, L.mi, L.g, best_twf, best_lds, p.tiles_x * p.tiles_y * sb, L.nblk, p.epi_lds); }
     // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
     static const char* trace_name = getenv("SNCAL_CONV_TRACE");
     unsigned long long* d_trace = nullptr; size_t n_trace = 0;
@@ -667,7 +657,7 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         n_trace = (size_t)p.tiles_x * p.tiles_y * sb * L.nblk * 16;
         if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
     }
-    bestv->launch[best_pf](p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -677,8 +667,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         if (FILE* f = fopen(getenv("SNCAL_CONV_TRACE_FILE") ? getenv("SNCAL_CONV_TRACE_FILE") : "conv_trace.bin", "wb")) { fwrite(h.data(), 8, n_trace, f); fclose(f); }
     }
     if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d,PF%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
-                              bestv->ni, L.mi, L.g, best_pf);
+        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
+                              bestv->ni, L.mi, L.g);
         static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
         if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
         const double px = (double)sb * to.H * to.W;

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -57,3 +59,42 @@ def test_product_path_fails_loudly_without_gpu_tensors():
     if not torch.cuda.is_available():
         with pytest.raises(sncal_amd._lib.SncalError):
             sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, algorithm='voter').solve_batch(torch.zeros(1, 57, 3))
+
+
+def test_file_interop_camera_json_and_lines_pickle(gold_dir, tmp_path):
+    """N1: camera_<frame>.json byte-compatible with what the reference's PredictionSaver writes for the same
+    camera (golden JSON dicts captured from the reference Camera), and the lines pickle in both layouts."""
+    import json
+    import sncal_amd
+    from sncal_amd import interop
+    g = np.load(os.path.join(gold_dir, 'camera.npz'), allow_pickle=True)
+    names = []
+    cams = []
+    for i in range(int(g['n'])):
+        ref = json.loads(str(g[f'{i}.json']))
+        cam = sncal_amd.Camera(960, 540)
+        cam.from_json_parameters(ref)
+        cams.append(cam if i % 2 == 0 else None)
+        names.append(f'{i:05d}.jpg')
+        if i % 2 == 0:
+            p = interop.camera_json_path(str(tmp_path), names[-1])
+            interop.save_camera_json(cam, p)
+            assert os.path.basename(p) == f'camera_{i:05d}.json'
+            # same serialisation call as PredictionSaver (json.dump(..., indent=4)) on the mirrored to_json_parameters(),
+            # whose values equal the reference's for the same camera (tests/test_oracle_goldens.py pins them)
+            assert open(p).read() == json.dumps(cam.to_json_parameters(), indent=4)
+            written = json.load(open(p))
+            assert list(written) == list(ref)                         # same keys, same order
+            for k in ref:
+                assert np.allclose(written[k], ref[k], rtol=1e-9, atol=1e-9), k
+            rt = interop.load_camera_json(p)
+            assert np.allclose(rt.position, cam.position) and np.allclose(rt.rotation, cam.rotation, atol=1e-12)
+    assert interop.save_cameras(cams, names, str(tmp_path / 'out')) == sum(c is not None for c in cams)
+    per_image = {'a.jpg': {'lines': {'Middle line': (0.5, 12.0), 'Side line top': (-0.01, 40.0)},
+                           'points': {'Middle line': [(10.0, 17.0, 0.9), (30.0, 27.0, 0.8)]}}}
+    for as_list in (True, False):
+        path = str(tmp_path / f'lines_{as_list}.pkl')
+        interop.save_lines_pickle(per_image, path, as_list=as_list)
+        assert interop.load_lines_pickle(path) == per_image
+    cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, lines_file=str(tmp_path / 'lines_True.pkl'))
+    assert 15 in cc.lines_data['a.jpg']          # Middle line x Side line top (intersections.py:28)

@@ -63,6 +63,7 @@ struct ConvParams {
     int cout;                        // real Cout (stores are masked beyond it)
     int out_cstride, out_coff;
     int cin_chunks;
+    int nblk;                        // output-channel blocks of MI*16 channels (grid = tiles * nblk, n-block fastest)
     int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
     unsigned halo_w_magic;           // floor(2^32 / halo width) + 1: pix / halo_w == umulhi(pix, magic) for pix < 2^16
     int tiles_x, tiles_y;
@@ -142,11 +143,13 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
+    // n-block fastest: the workgroups that share an input tile (and write the other channel slices of the same pixels)
+    // are dispatched together, so the tile is fetched into the L2s once in time and the output rows complete together
+    int tile = blockIdx.x / p.nblk;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile % p.tiles_y;
     const int n = tile / p.tiles_y;
-    const int nb = blockIdx.y;
+    const int nb = blockIdx.x - (blockIdx.x / p.nblk) * p.nblk;
     const int TWF = p.twf, TH = 4 * NI / TWF;
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
     const int oy00 = ty * TH, ox0 = tx * 16 * TWF;
@@ -199,9 +202,9 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     // co-resident wave runs MFMAs a VALU instruction issues every ~8 clk, and recomputing ~60 of them per piece
     // per chunk was the longest part of a staging round (per-workgroup trace, profiles/).  Padding slots and
     // outside-image pixels get an out-of-range offset -> the DMA writes zeros.
-    // (Kept for register tiles that leave room: <= 8 pieces per wave, <= 18 accumulator tiles.)
+    // (Kept for register tiles that leave room: <= 8 pieces per wave and <= 18 accumulator tiles, or <= 12 and <= 16.)
     constexpr int MAXH_ALL = (conv_max_halo_pieces(KS, STRIDE, NI, G) + 3) / 4;
-    constexpr bool HOIST = MAXH_ALL <= 8 && MI * NI <= 18;
+    constexpr bool HOIST = (MAXH_ALL <= 8 && MI * NI <= 18) || (MAXH_ALL <= 12 && MI * NI <= 16);
     constexpr int MAXH = HOIST ? MAXH_ALL : 1;
     const int cin_groups = (p.Cin + GE - 1) / GE;
     auto halo_voff = [&](int j, int c_lo) -> unsigned {      // c_lo: first k-group of the chunk, or 0 when hoisted
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
         }
     };
 
-    unsigned long long* const trc = p.trace ? p.trace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 : nullptr;
+    unsigned long long* const trc = p.trace ? p.trace + (size_t)blockIdx.x * 16 : nullptr;
     auto stamp = [&](int slot) { if (trc && tid == 0 && slot < 16) trc[slot] = __builtin_amdgcn_s_memtime(); };
     if (trc && tid == 0) trc[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
     stamp(1);
@@ -360,32 +363,33 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
             const size_t img_out = (size_t)n * p.Hout * p.Wout * p.out_cstride;
             const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
             __bf16* const out_img = reinterpret_cast<__bf16*>(p.out) + img_out;
+            // item -> (pixel, 8-channel group) offsets of the wave's NI fragments; the residual (when it was not
+            // prefetched before the main loop) is requested for ALL fragments first -- the fragment registers of the
+            // main loop are dead here -- so its latency is paid once, not once per staged block
+            unsigned off[NI][EITERS];
+            bf16x8 rr[RES_PF ? 1 : NI][RES_PF ? 1 : EITERS];
 #pragma unroll
-            for (int j0 = 0; j0 < NI; j0 += JB) {
-                // item -> (pixel, 8-channel group) offsets of this block; the residual (when it was not prefetched
-                // before the main loop) is requested for the whole block first, so its latency is paid once
-                unsigned off[JB][EITERS];
-                bf16x8 rr[RES_PF ? 1 : JB][RES_PF ? 1 : EITERS];
+            for (int j = 0; j < NI; ++j) {
+                const int f = wave * NI + j;
+                const int fr = f / TWF, fx = f - fr * TWF;
+                const int oy = oy00 + fr;
 #pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const int f = wave * NI + j0 + jj;
-                    const int fr = f / TWF, fx = f - fr * TWF;
-                    const int oy = oy00 + fr;
-#pragma unroll
-                    for (int it = 0; it < EITERS; ++it) {
-                        const int id = it * 64 + lane;
-                        const int px = id / GROUPS, grp = id - px * GROUPS;
-                        const int ox = ox0 + fx * 16 + px;
-                        const int co = nb * CO + grp * 8;
-                        const bool ok = (id < ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
-                        off[jj][it] = ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
-                        if constexpr (!RES_PF) {
-                            bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                            if (p.res && ok) r = *reinterpret_cast<const bf16x8*>(res_img + off[jj][it]);
-                            rr[jj][it] = r;
-                        }
+                for (int it = 0; it < EITERS; ++it) {
+                    const int id = it * 64 + lane;
+                    const int px = id / GROUPS, grp = id - px * GROUPS;
+                    const int ox = ox0 + fx * 16 + px;
+                    const int co = nb * CO + grp * 8;
+                    const bool ok = (id < ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
+                    off[j][it] = ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
+                    if constexpr (!RES_PF) {
+                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (p.res && ok) r = *reinterpret_cast<const bf16x8*>(res_img + off[j][it]);
+                        rr[j][it] = r;
                     }
                 }
+            }
+#pragma unroll
+            for (int j0 = 0; j0 < NI; j0 += JB) {
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
                 for (int jj = 0; jj < JB; ++jj) {
 #pragma unroll
                     for (int it = 0; it < EITERS; ++it) {
-                        if (off[jj][it] != 0xFFFFFFFFu) {
+                        if (off[j0 + jj][it] != 0xFFFFFFFFu) {
                             const int id = it * 64 + lane;
                             const int px = id / GROUPS, grp = id - px * GROUPS;
                             const float* sp = stg + (jj * 16 + px) * PITCH + grp * 8;
@@ -408,14 +412,14 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
                             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                             if (p.res) {
                                 bf16x8 r;
-                                if constexpr (RES_PF) r = res_pf[j0 + jj][it]; else r = rr[jj][it];
+                                if constexpr (RES_PF) r = res_pf[j0 + jj][it]; else r = rr[j0 + jj][it];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
                             }
                             bf16x8 q;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) q[e] = (__bf16)(p.relu ? fmaxf(v[e], 0.f) : v[e]);
-                            *reinterpret_cast<bf16x8*>(out_img + off[jj][it]) = q;
+                            *reinterpret_cast<bf16x8*>(out_img + off[j0 + jj][it]) = q;
                         }
                     }
                 }

@@ -657,7 +657,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         n_trace = (size_t)p.tiles_x * p.tiles_y * sb * L.nblk * 16;
         if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
     }
-    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb), (unsigned)L.nblk), best_lds, stream);
+    p.nblk = L.nblk;
+    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb * L.nblk)), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);

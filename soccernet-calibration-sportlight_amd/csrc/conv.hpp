@@ -63,7 +63,8 @@ struct ConvParams {
     int cout;                        // real Cout (stores are masked beyond it)
     int out_cstride, out_coff;
     int cin_chunks;
-    int nblk;                        // output-channel blocks of MI*16 channels (grid = tiles * nblk, n-block fastest)
+    int nblk;                        // output-channel blocks of MI*16 channels
+    unsigned n_work, per_xcd;        // work items = tiles * nblk; items per XCD (grid = 8 * per_xcd workgroups)
     int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
     unsigned halo_w_magic;           // floor(2^32 / halo width) + 1: pix / halo_w == umulhi(pix, magic) for pix < 2^16
     int tiles_x, tiles_y;
@@ -143,13 +144,17 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // n-block fastest: the workgroups that share an input tile (and write the other channel slices of the same pixels)
-    // are dispatched together, so the tile is fetched into the L2s once in time and the output rows complete together
-    int tile = blockIdx.x / p.nblk;
+    // Work item w = tile * nblk + n-block (n-block fastest: the workgroups that share an input tile and write the other
+    // channel slices of the same pixels run together).  XCD-aware order: block b runs on XCD b % 8 (observed dispatch
+    // rule, used for speed only), so XCD k walks the contiguous range [k, k+1) * per_xcd of work items -- neighbouring
+    // tiles (shared halo rows) and the n-blocks of one tile meet in the same L2 instead of eight different ones.
+    const unsigned w = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
+    if (w >= p.n_work) return;
+    int tile = (int)(w / (unsigned)p.nblk);
+    const int nb = (int)(w - (unsigned)tile * (unsigned)p.nblk);
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile % p.tiles_y;
     const int n = tile / p.tiles_y;
-    const int nb = blockIdx.x - (blockIdx.x / p.nblk) * p.nblk;
     const int TWF = p.twf, TH = 4 * NI / TWF;
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
     const int oy00 = ty * TH, ox0 = tx * 16 * TWF;

@@ -654,11 +654,13 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     static const char* trace_name = getenv("SNCAL_CONV_TRACE");
     unsigned long long* d_trace = nullptr; size_t n_trace = 0;
     if (trace_name && L.name == trace_name) {
-        n_trace = (size_t)p.tiles_x * p.tiles_y * sb * L.nblk * 16;
+        n_trace = (size_t)8 * ((p.tiles_x * p.tiles_y * sb * L.nblk + 7) / 8) * 16;
         if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
     }
     p.nblk = L.nblk;
-    bestv->launch(p, dim3((unsigned)(p.tiles_x * p.tiles_y * sb * L.nblk)), best_lds, stream);
+    p.n_work = (unsigned)(p.tiles_x * p.tiles_y * sb * L.nblk);
+    p.per_xcd = (p.n_work + 7) / 8;
+    bestv->launch(p, dim3(8 * p.per_xcd), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);

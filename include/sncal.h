@@ -200,6 +200,23 @@ int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pt
 int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
                     sncal_camera* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * H2 / N2  batched camera evaluation (accuracy@t of the SoccerNet calibration benchmark)
+ * replaces get_polylines / distance_to_polyline / evaluate_camera_prediction and the mirrored-label accuracy choice
+ *          baseline/evaluate_camera.py:14-229, 293-320 (the inner loop of src/models/hrnet/metrics.py:97-229)
+ *   d_cams (B) solved cameras (status 0 = missed frame); d_field (n_pts,3) fp64 sampled pitch model in class order,
+ *   d_class_start (n_cls+1) int32, d_mirror (n_cls) int32 = index of the left/right-symmetric class
+ *   (SoccerPitch.symetric_classes); d_gt (B,n_cls,max_gt,2) fp64 annotated points in pixels with counts
+ *   d_gt_cnt (B,n_cls); d_gt_extra (B) = annotated classes outside the pitch model (always false negatives).
+ *   d_out (B,12) fp32: confusion [TP,FP,FN,0] with plain labels, the same with mirrored labels, accuracy plain,
+ *   accuracy mirrored, chosen pass (1 or 2), evaluated flag (0 for a missed frame).
+ * The principal point is (img_w/2, img_h/2) as in Camera.from_json_parameters / project_point.
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const double* d_field, const int* d_class_start,
+                           const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
+                           const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
+                           float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

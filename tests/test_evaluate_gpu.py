@@ -1,0 +1,78 @@
+"""GPU: sncal_evaluate_cameras (batched accuracy@t metric) vs the reference capture and the oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import evaluate as oe
+from oracle import synth
+from test_oracle_goldens import _eval_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(sncal, frames, cuda):
+    """sncal_camera records for cameras given as (position, rotation, fx, fy) dicts; status 0 where None."""
+    Cam = sncal._lib.Camera
+    buf = (Cam * len(frames))()
+    for i, fr in enumerate(frames):
+        if fr is None:
+            continue
+        for k in range(3):
+            buf[i].position[k] = float(fr['position'][k])
+        for k in range(9):
+            buf[i].rotation[k] = float(np.asarray(fr['rotation']).reshape(-1)[k])
+        buf[i].fx, buf[i].fy = float(fr['f'][0]), float(fr['f'][1])
+        buf[i].cx, buf[i].cy = 479.5, 269.5            # the solver's centre; the metric uses (w/2, h/2) like the JSON
+        buf[i].status = 1
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8).reshape(len(frames), ctypes.sizeof(Cam)).copy()
+    return torch.from_numpy(raw).to(cuda)
+
+
+def test_evaluator_matches_reference_capture(sncal, cuda, gold_dir):
+    g, frames = _eval_frames(gold_dir)
+    ev = sncal.CameraEvaluator(cuda, 960, 540, threshold=5)
+    frames_m = frames[:4] + [None] + frames[4:]                     # one missed frame (no camera)
+    ann = [fr['gt'] if fr is not None else {} for fr in frames_m]
+    ann[0] = dict(ann[0]); ann[0]['Goal unknown'] = [(5.0, 5.0)]       # a class the pitch model does not have: +1 FN
+    out = ev.evaluate(_records(sncal, frames_m, cuda), ann).cpu().numpy()
+    k = 0
+    for i, fr in enumerate(frames_m):
+        if fr is None:
+            assert out[i, 11] == 0 and not out[i].any()
+            continue
+        c1, c2 = fr['conf1'].copy(), fr['conf2'].copy()
+        if i == 0:
+            c1[1, 0] += 1; c2[1, 0] += 1
+        assert np.array_equal(out[i, 0:4], c1.reshape(-1)) and np.array_equal(out[i, 4:8], c2.reshape(-1)), (i, out[i], c1, c2)
+        a1 = c1[0, 0] / c1.sum() if c1.sum() > 0 else 0.
+        a2 = c2[0, 0] / c2.sum() if c2.sum() > 0 else 0.
+        assert out[i, 8] == np.float32(a1) and out[i, 9] == np.float32(a2) and out[i, 10] == (1 if a1 > a2 else 2) and out[i, 11] == 1
+        k += 1
+    s = sncal.CameraEvaluator.summarize(out)
+    assert abs(s['completeness'] - 10 / 11) < 1e-12 and 0 < s['accuracy'] < 1 and abs(s['final_score'] - s['completeness'] * s['accuracy']) < 1e-12
+
+
+def test_evaluator_matches_oracle_on_random_cameras(sncal, cuda):
+    """64 synthetic cameras (synth.sample_camera) with perturbed predictions and subsampled annotations."""
+    rng = np.random.default_rng(3)
+    table = oe.field_table()
+    frames, ann, expect = [], [], []
+    for s in range(64):
+        cam = synth.sample_camera(np.random.Generator(np.random.PCG64(5000 + s)))
+        true_poly = oe.get_polylines(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.), 960, 540, table)
+        pred = dict(position=cam['position'] + rng.normal(0, 0.15, 3), rotation=cam['rotation'], f=(cam['f'] * (1 + rng.normal(0, 0.004)),) * 2)
+        gt = {c: [(x + rng.normal(0, 1.0), y + rng.normal(0, 1.0)) for (x, y) in v[::5][:8]] for c, v in true_poly.items() if rng.uniform() > 0.2}
+        frames.append(pred); ann.append(gt)
+        expect.append(oe.evaluate_frame(pred['position'], pred['rotation'], pred['f'][0], pred['f'][1], (480., 270.), gt, 5, table=table))
+    ev = sncal.CameraEvaluator(cuda)
+    out = ev.evaluate(_records(sncal, frames, cuda), ann).cpu().numpy()
+    bad = 0
+    for i, (conf, acc, c1, c2) in enumerate(expect):
+        if not (np.array_equal(out[i, 0:4], c1.reshape(-1)) and np.array_equal(out[i, 4:8], c2.reshape(-1))):
+            bad += 1
+    assert bad == 0, f'{bad} of 64 frames differ from the oracle'
+    accs = np.where(out[:, 10] == 1, out[:, 8], out[:, 9])
+    assert np.allclose(accs, [a for _, a, _, _ in expect], rtol=1e-6) and 0.1 < accs.mean() < 0.99

@@ -104,3 +104,29 @@ def test_line_join_golden(gold_dir):
             assert (float(v[0]), float(v[1])) == (ref[k][0], ref[k][1])
     arr = ol.keypoints_array(hl)
     assert arr.shape == (1, 30, 3) and arr[0, :, 2].sum() >= 10
+
+
+def _eval_frames(gold_dir):
+    g = np.load(os.path.join(gold_dir, 'evaluator_batch.npz'))
+    frames = []
+    for i in range(int(g['n'])):
+        gt = {str(c): [tuple(p) for p in g[f'{i}.gt.{c}']] for c in g[f'{i}.gt_classes']}
+        frames.append(dict(position=g[f'{i}.position'], rotation=g[f'{i}.rotation'], f=g[f'{i}.f'], pp=g[f'{i}.pp'], gt=gt,
+                           conf1=g[f'{i}.conf1'], conf2=g[f'{i}.conf2'], acc=g[f'{i}.acc'], npoly=g[f'{i}.npoly']))
+    return g, frames
+
+
+def test_evaluator_oracle_matches_reference_capture(gold_dir):
+    """N2 oracle: sampled pitch model, polylines, plain + mirrored confusion and accuracies of
+    baseline/evaluate_camera.py, captured from the imported reference (tools/make_golden.py evaluator_batch)."""
+    from oracle import evaluate as oe
+    g, frames = _eval_frames(gold_dir)
+    pts, start = oe.field_table()
+    assert np.array_equal(pts, g['field_points']) and np.array_equal(start, g['class_start']) and list(g['classes']) == oe.CLASSES
+    for fr in frames:
+        poly = oe.get_polylines(fr['position'], fr['rotation'], fr['f'][0], fr['f'][1], tuple(fr['pp']), 960, 540, (pts, start))
+        assert [len(poly.get(c, [])) for c in oe.CLASSES] == list(fr['npoly'])
+        conf, acc, c1, c2 = oe.evaluate_frame(fr['position'], fr['rotation'], fr['f'][0], fr['f'][1], tuple(fr['pp']), fr['gt'], 5,
+                                              table=(pts, start))
+        assert np.array_equal(c1, fr['conf1']) and np.array_equal(c2, fr['conf2']) and acc == max(fr['acc'])
+    assert any(fr['acc'][1] > fr['acc'][0] for fr in frames)          # the mirrored pass wins somewhere

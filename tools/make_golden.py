@@ -276,6 +276,86 @@ def gen_evaluator():
     print('evaluator ok')
 
 
+def gen_evaluator_batch():
+    """N2: the per-frame evaluation of evaluate_camera.py:293-320 (polylines, plain + mirrored confusion, accuracy
+    choice) captured from the reference for a batch of predicted cameras and synthetic annotations, plus the sampled
+    pitch model (SoccerPitch.sample_field_points(0.9)) -- the oracle must reproduce both exactly."""
+    from baseline.evaluate_camera import get_polylines as _get_polylines, evaluate_camera_prediction
+    from baseline.evaluate_extremities import mirror_labels
+    from baseline.soccerpitch import SoccerPitch
+    from baseline.camera import Camera
+    from oracle import synth, camera_math as cm, evaluate as oe
+
+    def get_polylines(js, w, h, sampling_factor):
+        # Camera.project_point multiplies distort()'s float32 by the focal length: a python float after
+        # from_json_parameters, i.e. float64 arithmetic under the reference's pinned numpy 1.24.2 but float32 under
+        # the numpy 2 installed here.  np.float64 fields give the pinned arithmetic under both.
+        cam = Camera(w, h)
+        cam.from_json_parameters(js)
+        cam.xfocal_length, cam.yfocal_length = np.float64(cam.xfocal_length), np.float64(cam.yfocal_length)
+        cam.principal_point = (np.float64(cam.principal_point[0]), np.float64(cam.principal_point[1]))
+        return _get_polylines(cam, w, h, sampling_factor=sampling_factor)
+    ref_tab = SoccerPitch().sample_field_points(0.9)
+    assert list(ref_tab) == oe.CLASSES and oe.SYMMETRIC == SoccerPitch.symetric_classes
+    pts, start = oe.field_table()
+    assert np.array_equal(pts, np.array([p for c in oe.CLASSES for p in ref_tab[c]]))
+    out = {'field_points': pts, 'class_start': start, 'classes': np.array(oe.CLASSES)}
+    n = 0
+    for seed in range(10):
+        rng = np.random.Generator(np.random.PCG64(900 + seed))
+        cam = synth.sample_camera(rng)
+        js_true = cm.to_json(cam['position'], cam['rotation'], cam['f'], cam['f'], (480., 270.))
+        lvl = 1 if seed == 7 else seed % 4
+        noise_pos = rng.normal(0, [0.0, 0.15, 0.6, 2.0][lvl], size=3)
+        fpred = cam['f'] * (1 + rng.normal(0, [0.0, 0.004, 0.02, 0.08][lvl]))
+        js_pred = cm.to_json(cam['position'] + noise_pos, cam['rotation'], fpred, fpred, (480., 270.))
+        poly_true = get_polylines(js_true, 960, 540, sampling_factor=0.9)
+        gt = {}
+        for k, v in poly_true.items():
+            if rng.uniform() < 0.15:
+                continue                                             # annotator missed this class -> false positive
+            step = int(rng.integers(2, 9))
+            sel = v[::step] if len(v) > 2 else v
+            gt[k] = [{'x': p['x'] + rng.normal(0, 0.7), 'y': p['y'] + rng.normal(0, 0.7)} for p in sel][:12]
+        if seed % 3 == 0:                                            # a class the camera cannot see -> false negative
+            for extra in oe.CLASSES:
+                if extra not in poly_true:
+                    gt[extra] = [{'x': 10.0, 'y': 20.0}, {'x': 30.0, 'y': 25.0}]
+                    break
+        if seed == 7:
+            gt = mirror_labels(gt)                                   # left/right swapped annotation: the mirrored pass wins
+        poly_pred = get_polylines(js_pred, 960, 540, sampling_factor=0.9)
+        c1, _, _ = evaluate_camera_prediction(poly_pred, gt, 5)
+        c2, _, _ = evaluate_camera_prediction(poly_pred, mirror_labels(gt), 5)
+        a1 = c1[0, 0] / c1.sum() if c1.sum() > 0 else 0.
+        a2 = c2[0, 0] / c2.sum() if c2.sum() > 0 else 0.
+        # the oracle on the same camera / annotations
+        from oracle.camera_math import rotation_from_ptr
+        R = rotation_from_ptr(np.deg2rad(js_pred['pan_degrees']), np.deg2rad(js_pred['tilt_degrees']), np.deg2rad(js_pred['roll_degrees']))
+        pos = np.array(js_pred['position_meters'])
+        mine = oe.get_polylines(pos, R, js_pred['x_focal_length'], js_pred['y_focal_length'], tuple(js_pred['principal_point']), 960, 540)
+        assert list(mine) == list(poly_pred), (list(mine), list(poly_pred))
+        for k in mine:
+            a = np.array([[p['x'], p['y']] for p in poly_pred[k]])
+            assert a.shape == np.array(mine[k]).shape and np.array_equal(a, np.array(mine[k])), k
+        gt_t = {k: [(p['x'], p['y']) for p in v] for k, v in gt.items()}
+        oc, oa, o1, o2 = oe.evaluate_frame(pos, R, js_pred['x_focal_length'], js_pred['y_focal_length'],
+                                           tuple(js_pred['principal_point']), gt_t, 5)
+        assert np.array_equal(o1, c1) and np.array_equal(o2, c2) and oa == max(a1, a2), (o1, c1, o2, c2)
+        out[f'{n}.position'] = pos; out[f'{n}.rotation'] = R
+        out[f'{n}.f'] = np.array([js_pred['x_focal_length'], js_pred['y_focal_length']])
+        out[f'{n}.pp'] = np.array(js_pred['principal_point'])
+        out[f'{n}.gt_classes'] = np.array(list(gt_t))
+        for k, v in gt_t.items():
+            out[f'{n}.gt.{k}'] = np.array(v)
+        out[f'{n}.conf1'] = c1; out[f'{n}.conf2'] = c2; out[f'{n}.acc'] = np.array([a1, a2])
+        out[f'{n}.npoly'] = np.array([len(poly_pred.get(c, [])) for c in oe.CLASSES])
+        n += 1
+    out['n'] = np.array(n)
+    np.savez_compressed(os.path.join(GOLD, 'evaluator_batch.npz'), **out)
+    print('evaluator_batch ok:', n, 'frames; accuracies', [tuple(np.round(out[f"{i}.acc"], 3)) for i in range(n)])
+
+
 def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, batch=1):
     from oracle import hrnet_ref as hr, decode as od
     cfg = hr.load_config(cfg_name)
@@ -334,7 +414,7 @@ def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'hrnet']
+    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'hrnet']
     if 'pitch' in which:
         gen_pitch()
     if 'decode' in which:
@@ -343,6 +423,8 @@ if __name__ == '__main__':
         gen_camera()
     if 'lines' in which:
         gen_lines()
+    if 'evaluator_batch' in which:
+        gen_evaluator_batch()
     if 'evaluator' in which:
         gen_evaluator()
     if 'hrnet' in which:

@@ -199,8 +199,6 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
         for (int i = wave; i < NKS * MI; i += 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(sw + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
     };
-    issue_weights(0, 0);      // chunk 0's weights first: the address arithmetic below runs under their flight
-
     // Halo pieces: piece j covers 64 consecutive 16-byte slots of the [pixel][SLOTS] image.  A lane's global
     // offset does not depend on the chunk (the chunk's channel offset rides in the scalar offset), so the
     // address arithmetic (two divisions, bounds tests) is done ONCE per workgroup and kept in registers: while a
@@ -256,7 +254,8 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     auto stamp = [&](int slot) { if (trc && tid == 0 && slot < 16) trc[slot] = __builtin_amdgcn_s_memtime(); };
     if (trc && tid == 0) trc[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
     stamp(1);
-    issue_halo(0, 0);         // chunk 0 is in flight: everything below until the wait is free
+    issue_weights(0, 0); issue_halo(0, 0);      // chunk 0 is in flight: everything below until the wait is free.  (Weights
+                                                // first measured 1.5 % faster than halo first, same box A/B.)
 
     // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
     // known up front, so the residual is requested now and arrives under the main loop

@@ -378,6 +378,8 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         const ConvVariant& V = net.variants[v];
         if (V.ks != L.k || V.stride != L.stride) continue;
         if (force_mi && L.k == 3 && L.stride == 1 && V.mi != force_mi && cout_frags % force_mi == 0) continue;
+        { static const int force_mi_s2 = getenv("SNCAL_FORCE_MI_S2") ? atoi(getenv("SNCAL_FORCE_MI_S2")) : 0;
+          if (force_mi_s2 && L.k == 3 && L.stride == 2 && L.cin_phys >= 48 && V.mi != force_mi_s2 && cout_frags % force_mi_s2 == 0) continue; }
         { static const int force_g = getenv("SNCAL_FORCE_G") ? atoi(getenv("SNCAL_FORCE_G")) : 0;
           if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue;
           static const int force_g48 = getenv("SNCAL_FORCE_G48") ? atoi(getenv("SNCAL_FORCE_G48")) : 0;
@@ -610,8 +612,10 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         if (force_ni && has_forced && L.k == 3 && L.stride == 1 && V.ni != force_ni) continue;
         const int F = 4 * V.ni;
         const size_t wchunk = (size_t)conv_nks(V.ks, V.g) * V.mi * 1024;
+        static const int force_twf = getenv("SNCAL_FORCE_TWF") ? atoi(getenv("SNCAL_FORCE_TWF")) : 0;   // tuning aid
         for (int twf = 1; twf <= F; twf *= 2) {
             if (F % twf) continue;
+            if (force_twf && L.k == 3 && L.stride == 1 && L.cin >= 96 && twf != force_twf) continue;
             const int th = F / twf;
             const size_t lds = conv_stage_bytes(V.ks, V.stride, V.ni, V.mi, V.g, twf);
             if (lds > 160 * 1024 || lds - wchunk > 64 * 1024) continue;   // halo tiles are capped at 64 DMA pieces

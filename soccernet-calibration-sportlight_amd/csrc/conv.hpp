@@ -65,7 +65,7 @@ struct ConvParams {
     int cin_chunks;
     int nblk;                        // output-channel blocks of MI*16 channels
     unsigned n_work, per_xcd;        // work items = tiles * nblk; items per XCD (grid = 8 * per_xcd workgroups)
-    int twf;                         // fragments per tile row; tile rows TH = 4*NI/twf
+    int twf, twf_log2;               // fragments per tile row (a power of two); tile rows TH = 4*NI/twf
     unsigned halo_w_magic;           // floor(2^32 / halo width) + 1: pix / halo_w == umulhi(pix, magic) for pix < 2^16
     int tiles_x, tiles_y;
     int relu, out_f32;
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile % p.tiles_y;
     const int n = tile / p.tiles_y;
-    const int TWF = p.twf, TH = 4 * NI / TWF;
+    const int TWF = p.twf, TWF_LOG2 = p.twf_log2, TH = (4 * NI) >> TWF_LOG2;     // TWF is a power of two: shifts, not the
+                                                                                 // ~25-instruction emulated integer division
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;
     const int oy00 = ty * TH, ox0 = tx * 16 * TWF;
     const int ix0 = ox0 * STRIDE - PAD;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int f = wave * NI + j;
-        const int fr = f / TWF, fx = f - fr * TWF;
+        const int fr = f >> TWF_LOG2, fx = f & (TWF - 1);
         boff[j] = ((fr * STRIDE) * HALO_W + (fx * 16 + ln) * STRIDE) * PS;
     }
     const int row_pitch = HALO_W * PS;
@@ -257,31 +258,39 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     issue_weights(0, 0); issue_halo(0, 0);      // chunk 0 is in flight: everything below until the wait is free.  (Weights
                                                 // first measured 1.5 % faster than halo first, same box A/B.)
 
-    // residual tile prefetch (epilogue A): the lane -> (pixel, 8-channel group) map of the coalesced epilogue is
-    // known up front, so the residual is requested now and arrives under the main loop
+    // Coalesced epilogue (A) bookkeeping, done ONCE up front: the lane -> (pixel, 8-channel group) map and the 32-bit
+    // element offsets of the wave's NI fragments inside its image serve the residual prefetch here and the stores at
+    // the end (0xFFFFFFFF = nothing to store).  With registers to spare (RES_PF) the residual tile is requested now
+    // and arrives under the main loop.
     constexpr int EPI_CO = MI * 16, EPI_GROUPS = EPI_CO / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;
     constexpr bool RES_PF = MI * NI <= 24 && conv_wgs_per_cu(KS, NI, MI, G) == 2;   // big accumulator sets leave no registers for the prefetch
     bf16x8 res_pf[RES_PF ? NI : 1][EPI_ITERS];
+    unsigned eoff[RES_PF ? NI : 1][EPI_ITERS];
     const bool epi_a = GE == 8 && p.epi_lds && !p.out_f32;
+    const size_t img_out = (size_t)n * p.Hout * p.Wout * p.out_cstride;
+    auto epi_offset = [&](int j, int it) -> unsigned {
+        const int f = wave * NI + j;
+        const int fr = f >> TWF_LOG2, fx = f & (TWF - 1);
+        const int oy = oy00 + fr;
+        const int id = it * 64 + lane;
+        const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
+        const int ox = ox0 + fx * 16 + px;
+        const int co = nb * EPI_CO + grp * 8;
+        const bool ok = (id < EPI_ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
+        return ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
+    };
     if constexpr (GE == 8 && RES_PF) {
-        if (epi_a && p.res) {
+        if (epi_a) {
+            const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int f = wave * NI + j;
-                    const int fr = f / TWF, fx = f - fr * TWF;
-                    const int oy = oy00 + fr;
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                    for (int it = 0; it < EPI_ITERS; ++it) {
-                        const int id = it * 64 + lane;
-                        const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
-                        const int ox = ox0 + fx * 16 + px;
-                        const int co = nb * EPI_CO + grp * 8;
-                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (id < EPI_ITEMS && oy < p.Hout && ox < p.Wout && co < p.cout)
-                            r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) +
-                                (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co);
-                        res_pf[j][it] = r;
-                    }
+                for (int it = 0; it < EPI_ITERS; ++it) {
+                    const unsigned o = epi_offset(j, it);
+                    eoff[j][it] = o;
+                    bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (p.res && o != 0xFFFFFFFFu) r = *reinterpret_cast<const bf16x8*>(res_img + o);
+                    res_pf[j][it] = r;
                 }
         }
     }
@@ -363,35 +372,27 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
             stamp(10);
             constexpr int JB = conv_epi_frags(KS, NI, MI, G);                              // fragments staged at a time
             float* stg = reinterpret_cast<float*>(smem) + wave * (JB * 16 * PITCH);
-            constexpr int GROUPS = CO / 8, ITEMS = 16 * GROUPS, EITERS = (ITEMS + 63) / 64;
-            const size_t img_out = (size_t)n * p.Hout * p.Wout * p.out_cstride;
+            constexpr int GROUPS = EPI_GROUPS, EITERS = EPI_ITERS;
             const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
             __bf16* const out_img = reinterpret_cast<__bf16*>(p.out) + img_out;
-            // item -> (pixel, 8-channel group) offsets of the wave's NI fragments; the residual (when it was not
-            // prefetched before the main loop) is requested for ALL fragments first -- the fragment registers of the
-            // main loop are dead here -- so its latency is paid once, not once per staged block
+            // item offsets: kept from the prologue when the residual was prefetched; otherwise computed here and the
+            // residual is requested for ALL fragments first -- the fragment registers of the main loop are dead --
+            // so its latency is paid once, not once per staged block
             unsigned off[NI][EITERS];
             bf16x8 rr[RES_PF ? 1 : NI][RES_PF ? 1 : EITERS];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int f = wave * NI + j;
-                const int fr = f / TWF, fx = f - fr * TWF;
-                const int oy = oy00 + fr;
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int it = 0; it < EITERS; ++it) {
-                    const int id = it * 64 + lane;
-                    const int px = id / GROUPS, grp = id - px * GROUPS;
-                    const int ox = ox0 + fx * 16 + px;
-                    const int co = nb * CO + grp * 8;
-                    const bool ok = (id < ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
-                    off[j][it] = ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
-                    if constexpr (!RES_PF) {
+                    if constexpr (RES_PF) {
+                        off[j][it] = eoff[j][it];
+                    } else {
+                        off[j][it] = epi_offset(j, it);
                         bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (p.res && ok) r = *reinterpret_cast<const bf16x8*>(res_img + off[j][it]);
+                        if (p.res && off[j][it] != 0xFFFFFFFFu) r = *reinterpret_cast<const bf16x8*>(res_img + off[j][it]);
                         rr[j][it] = r;
                     }
                 }
-            }
 #pragma unroll
             for (int j0 = 0; j0 < NI; j0 += JB) {
 #pragma unroll
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int f = wave * NI + j;
-        const int fr = f / TWF, fx = f - fr * TWF;
+        const int fr = f >> TWF_LOG2, fx = f & (TWF - 1);
         const int oy = oy00 + fr, ox = ox0 + fx * 16 + ln;
         if (oy >= p.Hout || ox >= p.Wout) continue;
         const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;

@@ -634,6 +634,8 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     if (!bestv) { set_error("no conv variant for %s (k=%d s=%d mi=%d g=%d)", L.name.c_str(), L.k, L.stride, L.mi, L.g); return SNCAL_ERR_STATE; }
     const int th = 4 * bestv->ni / best_twf;
     p.twf = best_twf;
+    p.twf_log2 = 0;
+    while ((1 << p.twf_log2) < best_twf) ++p.twf_log2;
     p.halo_w_magic = 0xFFFFFFFFu / (unsigned)((16 * best_twf - 1) * L.stride + L.k) + 1u;
     p.tiles_x = (to.W + 16 * best_twf - 1) / (16 * best_twf);
     p.tiles_y = (to.H + th - 1) / th;

@@ -65,6 +65,7 @@ struct ConvParams {
     int cin_chunks;
     int nblk;                        // output-channel blocks of MI*16 channels
     unsigned n_work, per_xcd;        // work items = tiles * nblk; items per XCD (grid = 8 * per_xcd workgroups)
+    unsigned nblk_magic, tiles_x_magic, tiles_y_magic;   // conv_magic() of nblk, tiles_x, tiles_y
     int twf, twf_log2;               // fragments per tile row (a power of two); tile rows TH = 4*NI/twf
     unsigned halo_w_magic;           // floor(2^32 / halo width) + 1: pix / halo_w == umulhi(pix, magic) for pix < 2^16
     int tiles_x, tiles_y;
@@ -90,6 +91,11 @@ __host__ __device__ constexpr int epi_frags(int NI, int wgs_per_cu) { return wgs
 
 __host__ __device__ constexpr int conv_nks(int KS, int G) { return (KS * KS * G + 3) / 4; }
 
+
+// x / d for wave-uniform runtime d without the ~25-instruction emulated integer division: multiply-high by the
+// host-computed reciprocal floor(2^32 / d) + 1 (exact while x * d < 2^32); d = 1 has no 32-bit reciprocal
+__host__ __device__ inline unsigned conv_magic(unsigned d) { return d <= 1 ? 0u : 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ unsigned conv_udiv(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
 
 // upper bound of the 1 KB halo pieces of a tile, over the tile shapes the host may pick (TWF = 1, 2, 4, ...)
 __host__ __device__ constexpr int conv_max_halo_pieces(int KS, int S, int NI, int G) {
@@ -150,11 +156,13 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     // tiles (shared halo rows) and the n-blocks of one tile meet in the same L2 instead of eight different ones.
     const unsigned w = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
     if (w >= p.n_work) return;
-    int tile = (int)(w / (unsigned)p.nblk);
-    const int nb = (int)(w - (unsigned)tile * (unsigned)p.nblk);
-    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y;
-    const int n = tile / p.tiles_y;
+    unsigned tile = conv_udiv(w, (unsigned)p.nblk, p.nblk_magic);
+    const int nb = (int)(w - tile * (unsigned)p.nblk);
+    unsigned q = conv_udiv(tile, (unsigned)p.tiles_x, p.tiles_x_magic);
+    const int tx = (int)(tile - q * (unsigned)p.tiles_x);
+    const unsigned n_u = conv_udiv(q, (unsigned)p.tiles_y, p.tiles_y_magic);
+    const int ty = (int)(q - n_u * (unsigned)p.tiles_y);
+    const int n = (int)n_u;
     const int TWF = p.twf, TWF_LOG2 = p.twf_log2, TH = (4 * NI) >> TWF_LOG2;     // TWF is a power of two: shifts, not the
                                                                                  // ~25-instruction emulated integer division
     const int HALO_W = (16 * TWF - 1) * STRIDE + KS, HALO_H = (TH - 1) * STRIDE + KS;

@@ -666,6 +666,7 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.nblk = L.nblk;
     p.n_work = (unsigned)(p.tiles_x * p.tiles_y * sb * L.nblk);
     p.per_xcd = (p.n_work + 7) / 8;
+    p.nblk_magic = conv_magic((unsigned)L.nblk); p.tiles_x_magic = conv_magic((unsigned)p.tiles_x); p.tiles_y_magic = conv_magic((unsigned)p.tiles_y);
     bestv->launch(p, dim3(8 * p.per_xcd), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {

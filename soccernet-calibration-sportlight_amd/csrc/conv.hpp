@@ -37,7 +37,9 @@
 // resident workgroup.  Explicit prefetch of the next chunk (halo only, or halo + weights, double-buffered in LDS)
 // was built and measured: the waits disappear but the DMA issue cost (~100 clk per 1 KB piece on the issuing wave)
 // moves into the MFMA phase and the doubled LDS footprint costs a resident workgroup -- never faster than single
-// buffers with two or three workgroups per CU, so the kernel keeps single buffers only.
+// buffers with two or three workgroups per CU, so the kernel keeps single buffers only.  An L2 prefetch of a future
+// workgroup's halo (one dword per 128-byte line through LDS-DMA, issued under the last MFMA phase) left the first
+// round's wait unchanged: that wait is the prologue's own VALU work and DMA issue, not a cold-miss latency.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

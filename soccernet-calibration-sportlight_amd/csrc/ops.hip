@@ -8,6 +8,7 @@
 //                     (hrnet.py:329, line/hrnet.py:101)
 // All are HBM-bound streaming kernels: one 16-byte vector per lane, grid-stride.
 #include "common.hpp"
+#include <algorithm>
 #include "ops.hpp"
 
 namespace sncal {
@@ -26,14 +27,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N,
                                                            int C, int H, int W) {
     constexpr int GE = Vec<T>::GE;
-    const size_t total = (size_t)N * H * W;
-    for (size_t p = blockIdx.x * 256ull + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
-        const size_t hw = (size_t)H * W;
-        const size_t n = p / hw, r = p - n * hw;
+    const unsigned hw = (unsigned)(H * W);
+    const size_t n = blockIdx.y;                                   // one image per grid row: no per-element division
+    for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < hw; r += gridDim.x * 256u) {
         typename Vec<T>::type v;
 #pragma unroll
         for (int c = 0; c < GE; ++c) v[c] = (T)(c < C ? x[(n * C + c) * hw + r] : 0.0f);
-        *reinterpret_cast<typename Vec<T>::type*>(y + p * GE) = v;
+        *reinterpret_cast<typename Vec<T>::type*>(y + (n * hw + r) * GE) = v;
     }
 }
 
@@ -81,19 +81,25 @@ __device__ __forceinline__ void bilinear_acc(float (&acc)[Vec<T>::GE], const T* 
     }
 }
 
+// x / d by multiply-high with the host-computed reciprocal floor(2^32 / d) + 1 (exact while x * d < 2^32): the emulated
+// integer division costs ~25 VALU instructions in 32 bits and several times that in 64 bits -- with six of them per
+// 16-byte element this kernel was instruction-bound at 3 TB/s
+__device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) {
     constexpr int GE = Vec<T>::GE;
     typedef typename Vec<T>::type V;
-    const int cg = p.C / GE;
-    const size_t total = (size_t)p.N * p.H * p.W * cg;
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c0 = (int)(i % cg) * GE;
-        size_t pix = i / cg;
-        const int ox = (int)(pix % p.W);
-        size_t t = pix / p.W;
-        const int oy = (int)(t % p.H);
-        const int n = (int)(t / p.H);
+    const unsigned cg = (unsigned)(p.C / GE);
+    const unsigned per_img = (unsigned)(p.H * p.W) * cg;           // 16-byte elements of one image (< 2^31)
+    const int n = blockIdx.y;
+    const size_t img_pix = (size_t)n * p.H * p.W;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per_img; i += gridDim.x * 256u) {
+        const unsigned pl = udiv_magic(i, cg, p.cg_magic);
+        const int c0 = (int)(i - pl * cg) * GE;
+        const unsigned uy = udiv_magic(pl, (unsigned)p.W, p.w_magic);
+        const int oy = (int)uy, ox = (int)(pl - uy * (unsigned)p.W);
+        const size_t pix = img_pix + pl;
         float acc[GE];
         if (p.base) {
             const V b = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.base) + pix * p.C + c0);
@@ -167,9 +173,9 @@ static inline int grid_for(size_t items) {
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s) {
     const size_t total = (size_t)N * H * W;
     if (dtype == SNCAL_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, N, C, H, W);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (float*)y, N, C, H, W);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }
@@ -184,13 +190,20 @@ int launch_u8hwc_to_nhwc(int dtype, const unsigned char* x, void* y, int N, int 
     return SNCAL_OK;
 }
 
-int launch_upsample_add(int dtype, const UpsampleAddParams& p, hipStream_t s) {
+int launch_upsample_add(int dtype, const UpsampleAddParams& p0, hipStream_t s) {
+    UpsampleAddParams p = p0;
     const int ge = dtype == SNCAL_BF16 ? 8 : 4;
-    const size_t total = (size_t)p.N * p.H * p.W * (p.C / ge);
+    const unsigned cg = (unsigned)(p.C / ge);
+    const size_t per_img = (size_t)p.H * p.W * cg;
+    // multiply-high division is exact while dividend * divisor < 2^32: (element index, cg) and (pixel index, W)
+    if (per_img >= (1ull << 31) || per_img * cg >= (1ull << 32) || (size_t)p.H * p.W * p.W >= (1ull << 32)) { set_error("upsample_add: image of %d x %d x %d is too large", p.H, p.W, p.C); return SNCAL_ERR_ARG; }
+    p.cg_magic = cg <= 1 ? 0u : 0xFFFFFFFFu / cg + 1u;
+    p.w_magic = p.W <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)p.W + 1u;
+    const dim3 grid((unsigned)std::min<size_t>((per_img + 255) / 256, 2048), (unsigned)p.N);
     if (dtype == SNCAL_BF16)
-        hipLaunchKernelGGL(upsample_add_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(upsample_add_kernel<__bf16>, grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(upsample_add_kernel<float>, grid, dim3(256), 0, s, p);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

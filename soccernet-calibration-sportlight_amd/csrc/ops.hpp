@@ -15,6 +15,7 @@ struct UpsampleAddParams {
     int N, H, W, C;
     int out_cstride, out_coff;
     int relu;
+    unsigned cg_magic, w_magic;   // filled by the launcher: reciprocals of C/GE and W for the index decode
 };
 
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s);

@@ -73,11 +73,36 @@ __device__ __forceinline__ void bilinear_acc(float (&acc)[Vec<T>::GE], const T* 
     const V v01 = *reinterpret_cast<const V*>(src + (base + (size_t)ly.i0 * Ws + lx.i1) * C + c0);
     const V v10 = *reinterpret_cast<const V*>(src + (base + (size_t)ly.i1 * Ws + lx.i0) * C + c0);
     const V v11 = *reinterpret_cast<const V*>(src + (base + (size_t)ly.i1 * Ws + lx.i1) * C + c0);
+    if constexpr (GE == 8) {
+        // bf16: the kernel is VALU-bound (unpack + 6 multiply-adds per tap-channel).  v_perm_b32 pairs the same
+        // channel of two taps and v_dot2_f32_bf16 applies both weights with fp32 accumulation: 4 instructions per
+        // channel instead of 10; the four weights are rounded to bf16 like the taps they multiply.
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 wt, wb;
+        wt[0] = (__bf16)(lx.w0 * ly.w0); wt[1] = (__bf16)(lx.w1 * ly.w0);
+        wb[0] = (__bf16)(lx.w0 * ly.w1); wb[1] = (__bf16)(lx.w1 * ly.w1);
+        const uint4 a0 = __builtin_bit_cast(uint4, v00), a1 = __builtin_bit_cast(uint4, v01);
+        const uint4 b0 = __builtin_bit_cast(uint4, v10), b1 = __builtin_bit_cast(uint4, v11);
+        const unsigned ta0[4] = {a0.x, a0.y, a0.z, a0.w}, ta1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const unsigned tb0[4] = {b0.x, b0.y, b0.z, b0.w}, tb1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int e = 0; e < GE; ++e) {
-        const float top = (float)v00[e] * lx.w0 + (float)v01[e] * lx.w1;
-        const float bot = (float)v10[e] * lx.w0 + (float)v11[e] * lx.w1;
-        acc[e] += top * ly.w0 + bot * ly.w1;
+        for (int pr = 0; pr < 4; ++pr) {
+            const bf16x2 tl = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(ta1[pr], ta0[pr], 0x05040100u));
+            const bf16x2 th = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(ta1[pr], ta0[pr], 0x07060302u));
+            const bf16x2 bl = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(tb1[pr], tb0[pr], 0x05040100u));
+            const bf16x2 bh = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(tb1[pr], tb0[pr], 0x07060302u));
+            acc[2 * pr] = __builtin_amdgcn_fdot2_f32_bf16(tl, wt, acc[2 * pr], false);
+            acc[2 * pr] = __builtin_amdgcn_fdot2_f32_bf16(bl, wb, acc[2 * pr], false);
+            acc[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(th, wt, acc[2 * pr + 1], false);
+            acc[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(bh, wb, acc[2 * pr + 1], false);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < GE; ++e) {
+            const float top = (float)v00[e] * lx.w0 + (float)v01[e] * lx.w1;
+            const float bot = (float)v10[e] * lx.w0 + (float)v11[e] * lx.w1;
+            acc[e] += top * ly.w0 + bot * ly.w1;
+        }
     }
 }
 

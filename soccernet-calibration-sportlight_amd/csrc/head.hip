@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
     const int lane = threadIdx.x & 63, g = lane >> 4, ln = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tile = blockIdx.x;
-    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y;
-    const int n = tile / p.tiles_y;
+    // multiply-high by host reciprocals instead of emulated integer divisions (~25 VALU instructions each)
+    const unsigned q1 = p.tiles_x == 1 ? (unsigned)tile : __umulhi((unsigned)tile, p.tiles_x_magic);
+    const int tx = tile - (int)q1 * p.tiles_x;
+    const unsigned q2 = p.tiles_y == 1 ? q1 : __umulhi(q1, p.tiles_y_magic);
+    const int ty = (int)q1 - (int)q2 * p.tiles_y;
+    const int n = (int)q2;
     const int oy0 = ty * HEAD_TH, ox0 = tx * 16;
     const __bf16* direct = reinterpret_cast<const __bf16*>(p.direct);
 
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
                 if ((cursor & 3) != wave) continue;
                 const int k = cursor >> 2;
                 const int slot = i * 64 + lane, pi = slot >> 2, piece = slot & 3;
-                const int ly = pi / bw[s], lx = pi - ly * bw[s];
+                const int ly = (pi * ((65536 / bw[s]) + 1)) >> 16, lx = pi - ly * bw[s];     // pi < 64, bw <= 64: exact; bw[s] is
+                                                                                             // block-uniform, its reciprocal is scalar work
                 const unsigned v = pi < npx ? (unsigned)((((by0[s] + ly) * p.Ws[s] + bx0[s] + lx) * p.HP) * 2 + piece * 16) : 0x80000000u;
 #pragma unroll
                 for (int kk = 0; kk < HEAD_MAX_DMA; ++kk)
@@ -312,6 +316,8 @@ int launch_head_fused(const HeadParams& p, int m2, hipStream_t s) {
     if (!np) { set_error("fused head: the gather sources are not down-scaled branches"); return SNCAL_ERR_ARG; }
     q.tiles_x = (p.W + 15) / 16;
     q.tiles_y = (p.H + 4 * np - 1) / (4 * np);
+    q.tiles_x_magic = q.tiles_x <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_x + 1u;
+    q.tiles_y_magic = q.tiles_y <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_y + 1u;
     const unsigned blocks = (unsigned)(q.tiles_x * q.tiles_y * p.N);
     int rc;
     if (m2 == 2) rc = np == 2 ? launch_m2<2, 2>(q, blocks, s) : launch_m2<2, 1>(q, blocks, s);

@@ -27,6 +27,7 @@ struct HeadParams {
     int N, H, W;
     int HP, NQ, LC;                // padded hidden width (800), HP/32, padded class count (M2*16)
     int tiles_x, tiles_y;          // filled by the launcher
+    unsigned tiles_x_magic, tiles_y_magic;   // filled by the launcher: floor(2^32 / d) + 1
 };
 
 int launch_head_fused(const HeadParams& p, int m2, hipStream_t s);

@@ -34,7 +34,8 @@ typedef enum {
     SNCAL_ERR_ARG = -1,        /* invalid argument (shape, null pointer, unsupported size)  */
     SNCAL_ERR_HIP = -2,        /* a HIP runtime call or kernel launch failed                */
     SNCAL_ERR_STATE = -3,      /* object not finalised / weights missing                    */
-    SNCAL_ERR_WORKSPACE = -4   /* caller workspace too small                                */
+    SNCAL_ERR_WORKSPACE = -4,  /* caller workspace too small                                */
+    SNCAL_ERR_UNSUPPORTED = -5 /* well-formed input that this build does not handle (e.g. progressive JPEG) */
 } sncal_status;
 
 typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1 } sncal_dtype;
@@ -216,6 +217,44 @@ int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const double* d_fi
                            const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
                            const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
                            float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * N3  input stage: JPEG bytes -> BGR uint8 frames on the device
+ * replaces cv2.imread(path)            src/utils/make_submit.py:62, src/utils/export_line_result.py:176
+ *          (opencv-python==4.7.0.72, requirements.txt:5 -> libjpeg-turbo defaults: JDCT_ISLOW, fancy upsampling)
+ * The serial part of a JPEG -- marker parsing and Huffman decoding -- runs on host threads into pinned memory;
+ * everything with pixel parallelism runs on the device, bit-exactly as libjpeg-turbo computes it: dequantisation +
+ * jidctint.c jpeg_idct_islow, jdsample.c h2v2/h2v1 fancy upsampling, jdcolor.c YCbCr->RGB.  The output (B,H,W,3) BGR
+ * is the input of sncal_hrnet_forward_u8.
+ * Supported: 8-bit sequential DCT (SOF0/SOF1), Huffman, one interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
+ * restart intervals.  Progressive / arithmetic / CMYK / 4:4:0 / multi-scan -> SNCAL_ERR_UNSUPPORTED; damaged
+ * streams -> SNCAL_ERR_ARG; the message names the frame.  EXIF orientation is not applied.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sncal_jpeg sncal_jpeg;
+typedef struct {
+    int32_t width, height;
+    int32_t components;          /* 1 (grey) or 3 (YCbCr) */
+    int32_t h_samp, v_samp;      /* luma sampling factors: 1x1 = 4:4:4, 2x1 = 4:2:2, 2x2 = 4:2:0 */
+    int32_t restart_interval;    /* MCUs, 0 = none */
+    int32_t blocks[3];           /* 8x8 coefficient blocks per component (MCU padded) */
+} sncal_jpeg_info;
+
+/* Host only (no GPU needed): parse the headers of one JPEG. */
+int sncal_jpeg_probe(const unsigned char* data, size_t len, sncal_jpeg_info* info);
+/* Host only: headers + Huffman decode of one JPEG into quantised coefficient blocks, int16, natural (row-major)
+ * order, component after component, each (block_rows, block_cols, 64) -- the layout the device kernels read.
+ * `cap` = capacity of `coef` in int16 elements; info->blocks tells how much was written. */
+int sncal_jpeg_entropy_decode(const unsigned char* data, size_t len, int16_t* coef, size_t cap,
+                              sncal_jpeg_info* info);
+/* Decoder for batches of up to max_batch frames of exactly height x width pixels (the reference stacks its frames
+ * into one tensor, make_submit.py:63).  n_threads host workers for the entropy decode (0 = hardware concurrency,
+ * capped at 32).  Owns pinned staging (double-buffered) and the device coefficient / sample-plane buffers. */
+int sncal_jpeg_create(int max_batch, int height, int width, int n_threads, sncal_jpeg** out);
+void sncal_jpeg_destroy(sncal_jpeg* dec);
+/* data[b], len[b]: host pointers to B encoded frames.  d_bgr: (B,height,width,3) uint8 on the device.  The host
+ * part runs inside the call; the copy and the two kernels are enqueued on `stream`. */
+int sncal_jpeg_decode(sncal_jpeg* dec, const unsigned char* const* data, const size_t* len, int B,
+                      unsigned char* d_bgr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,13 @@ class VoterCfg(ctypes.Structure):
                 ('min_focal_length', ctypes.c_double), ('img_w', ctypes.c_int), ('img_h', ctypes.c_int)]
 
 
+class JpegInfo(ctypes.Structure):
+    """sncal_jpeg_info."""
+    _fields_ = [('width', ctypes.c_int32), ('height', ctypes.c_int32), ('components', ctypes.c_int32),
+                ('h_samp', ctypes.c_int32), ('v_samp', ctypes.c_int32), ('restart_interval', ctypes.c_int32),
+                ('blocks', ctypes.c_int32 * 3)]
+
+
 # name -> (restype, argtypes); must list every function include/sncal.h declares
 SIGNATURES = {
     'sncal_version': (ctypes.c_int, []),
@@ -78,6 +85,12 @@ SIGNATURES = {
     'sncal_pnp_refine_lm': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                            ctypes.c_double, vp]),
     'sncal_solve_pnp': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    'sncal_jpeg_probe': (ctypes.c_int, [vp, ctypes.c_size_t, ctypes.POINTER(JpegInfo)]),
+    'sncal_jpeg_entropy_decode': (ctypes.c_int, [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.POINTER(JpegInfo)]),
+    'sncal_jpeg_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
+    'sncal_jpeg_destroy': (None, [vp]),
+    'sncal_jpeg_decode': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.c_int, vp, vp]),
     'sncal_calibrate': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp]),
 }
 

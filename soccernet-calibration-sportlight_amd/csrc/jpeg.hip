@@ -1,0 +1,559 @@
+// JPEG input stage: encoded frames -> (B,H,W,3) BGR uint8 on the device, the array cv2.imread returns
+// in /root/reference/src/utils/make_submit.py:62 and /root/reference/src/utils/export_line_result.py:176.
+//
+// cv2 (opencv-python==4.7.0.72, /root/reference/requirements.txt:5) decodes with its bundled libjpeg-turbo and the
+// library defaults: JDCT_ISLOW, fancy upsampling, YCbCr->RGB in 16-bit fixed point.  Split here by what parallelises:
+//   host   marker parsing + Huffman decode (bit-serial by construction; one frame per worker thread) into quantised
+//          int16 coefficient blocks in pinned memory -- 3 bytes per pixel for 4:2:0, the same size as the decoded frame
+//   device jpeg_idct_kernel    dequantise + jidctint.c jpeg_idct_islow, 8 lanes per 8x8 block (a column each, then a
+//                              row each, workspace in LDS), samples range-limited as jdmaster.c's table does
+//          jpeg_colour_kernel  jdsample.c h2v2 / h2v1 fancy upsampling (triangle filter with libjpeg's alternating
+//                              rounding bias, edge replication) fused with jdcolor.c ycc_rgb_convert, 4 pixels a lane
+// Integer arithmetic end to end: the result is bit-identical to libjpeg-turbo's (tests/test_jpeg_gpu.py).
+// Both kernels are HBM-trivial (~6 bytes moved per pixel); the stage exists to take the IDCT / upsampling / colour
+// work -- more than half of a CPU decode -- and the float conversion off the host.
+#include "common.hpp"
+#include "../../include/sncal.h"
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ host: parsing
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {                       // T.81 annex C canonical code; 9-bit direct table + length search beyond
+    bool present = false;
+    uint16_t fast[512];             // (length << 8) | symbol, 0 = longer than 9 bits
+    int32_t maxcode[18];            // largest code of each length, -1 = none
+    int32_t valoff[17];             // symbol index = code + valoff[length]
+    uint8_t vals[256];
+};
+
+struct Comp { int id, h, v, tq, td, ta; };
+
+struct Header {
+    int width = 0, height = 0, ncomp = 0, restart = 0;
+    Comp comp[3];
+    uint16_t qt[4][64];             // natural order
+    bool qt_present[4] = {false, false, false, false};
+    Huff huff[2][4];                // [dc/ac][id]
+    const uint8_t* scan = nullptr;
+    const uint8_t* end = nullptr;
+    int mcus_x = 0, mcus_y = 0;
+    int bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+};
+
+struct Fail { int code; std::string msg; };
+#define JFAIL(code_, ...)                                            \
+    do { char b_[200]; snprintf(b_, sizeof(b_), __VA_ARGS__); return Fail{code_, b_}; } while (0)
+inline Fail ok() { return Fail{SNCAL_OK, std::string()}; }
+
+bool build_huff(Huff& t, const uint8_t* counts, const uint8_t* symbols, int n) {
+    memset(t.fast, 0, sizeof(t.fast));
+    memcpy(t.vals, symbols, n);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        t.valoff[len] = k - code;
+        for (int i = 0; i < counts[len - 1]; ++i, ++code, ++k) {
+            if (code >= (1 << len)) return false;
+            if (len <= 9) {
+                const int lo = code << (9 - len);
+                for (int f = 0; f < (1 << (9 - len)); ++f) t.fast[lo + f] = (uint16_t)((len << 8) | symbols[k]);
+            }
+        }
+        t.maxcode[len] = counts[len - 1] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7fffffff;
+    t.present = true;
+    return true;
+}
+
+Fail parse_header(const uint8_t* d, size_t len, Header& h) {
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) JFAIL(SNCAL_ERR_ARG, "not a JPEG (no SOI marker)");
+    size_t i = 2;
+    bool have_frame = false;
+    for (;;) {
+        if (i + 4 > len) JFAIL(SNCAL_ERR_ARG, "truncated before the scan");
+        if (d[i] != 0xFF) JFAIL(SNCAL_ERR_ARG, "marker expected at byte %zu", i);
+        const int m = d[i + 1];
+        if (m == 0xFF) { ++i; continue; }
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { i += 2; continue; }
+        const size_t L = ((size_t)d[i + 2] << 8) | d[i + 3];
+        if (L < 2 || i + 2 + L > len) JFAIL(SNCAL_ERR_ARG, "truncated segment (marker 0x%02X)", m);
+        const uint8_t* s = d + i + 4;
+        const size_t n = L - 2;
+        if (m == 0xDB) {
+            size_t j = 0;
+            while (j < n) {
+                const int pq = s[j] >> 4, tq = s[j] & 15;
+                ++j;
+                if (tq > 3 || j + (pq ? 128 : 64) > n) JFAIL(SNCAL_ERR_ARG, "bad quantisation table segment");
+                for (int k = 0; k < 64; ++k) {
+                    if (pq) { h.qt[tq][kZigzag[k]] = (uint16_t)((s[j] << 8) | s[j + 1]); j += 2; }
+                    else    { h.qt[tq][kZigzag[k]] = s[j]; j += 1; }
+                }
+                h.qt_present[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t j = 0;
+            while (j < n) {
+                if (j + 17 > n) JFAIL(SNCAL_ERR_ARG, "bad Huffman table segment");
+                const int tc = s[j] >> 4, th = s[j] & 15;
+                int cnt = 0;
+                for (int k = 0; k < 16; ++k) cnt += s[j + 1 + k];
+                if (tc > 1 || th > 3 || cnt > 256 || j + 17 + cnt > n) JFAIL(SNCAL_ERR_ARG, "bad Huffman table segment");
+                if (!build_huff(h.huff[tc][th], s + j + 1, s + j + 17, cnt)) JFAIL(SNCAL_ERR_ARG, "over-subscribed Huffman code");
+                j += 17 + cnt;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (n < 6) JFAIL(SNCAL_ERR_ARG, "bad frame header");
+            if (s[0] != 8) JFAIL(SNCAL_ERR_UNSUPPORTED, "%d-bit samples (only 8-bit JPEG is supported)", s[0]);
+            h.height = (s[1] << 8) | s[2];
+            h.width = (s[3] << 8) | s[4];
+            h.ncomp = s[5];
+            if (h.ncomp != 1 && h.ncomp != 3) JFAIL(SNCAL_ERR_UNSUPPORTED, "%d colour components (grey or YCbCr only)", h.ncomp);
+            if (n < 6 + 3 * (size_t)h.ncomp) JFAIL(SNCAL_ERR_ARG, "bad frame header");
+            for (int c = 0; c < h.ncomp; ++c)
+                h.comp[c] = Comp{s[6 + 3 * c], s[7 + 3 * c] >> 4, s[7 + 3 * c] & 15, s[8 + 3 * c], 0, 0};
+            have_frame = true;
+        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+            JFAIL(SNCAL_ERR_UNSUPPORTED, "JPEG process SOF%d (only sequential Huffman DCT, SOF0/SOF1, is supported)", m - 0xC0);
+        } else if (m == 0xCC) {
+            JFAIL(SNCAL_ERR_UNSUPPORTED, "arithmetic coding");
+        } else if (m == 0xDD) {
+            if (n < 2) JFAIL(SNCAL_ERR_ARG, "bad DRI segment");
+            h.restart = (s[0] << 8) | s[1];
+        } else if (m == 0xDA) {
+            if (!have_frame) JFAIL(SNCAL_ERR_ARG, "scan before frame header");
+            if (n < 1 || s[0] != h.ncomp) JFAIL(SNCAL_ERR_UNSUPPORTED, "multi-scan file (one interleaved scan is supported)");
+            if (n < 1 + 2 * (size_t)h.ncomp + 3) JFAIL(SNCAL_ERR_ARG, "bad scan header");
+            for (int c = 0; c < h.ncomp; ++c) {
+                if (s[1 + 2 * c] != h.comp[c].id) JFAIL(SNCAL_ERR_UNSUPPORTED, "scan components out of frame order");
+                h.comp[c].td = s[2 + 2 * c] >> 4;
+                h.comp[c].ta = s[2 + 2 * c] & 15;
+            }
+            h.scan = d + i + 2 + L;
+            h.end = d + len;
+            break;
+        } else if (m == 0xD9) {
+            JFAIL(SNCAL_ERR_ARG, "end of image before any scan");
+        }
+        i += 2 + L;
+    }
+    if (h.width <= 0 || h.height <= 0) JFAIL(SNCAL_ERR_ARG, "empty frame");
+    if (h.ncomp == 1) {
+        h.comp[0].h = h.comp[0].v = 1;              // a single-component scan is never interleaved
+    } else {
+        const bool chroma11 = h.comp[1].h == 1 && h.comp[1].v == 1 && h.comp[2].h == 1 && h.comp[2].v == 1;
+        const int lh = h.comp[0].h, lv = h.comp[0].v;
+        if (!chroma11 || !((lh == 1 && lv == 1) || (lh == 2 && lv == 1) || (lh == 2 && lv == 2)))
+            JFAIL(SNCAL_ERR_UNSUPPORTED, "sampling factors %dx%d,%dx%d,%dx%d (4:4:4, 4:2:2, 4:2:0 are supported)", lh, lv,
+                  h.comp[1].h, h.comp[1].v, h.comp[2].h, h.comp[2].v);
+    }
+    for (int c = 0; c < h.ncomp; ++c) {
+        if (h.comp[c].tq > 3 || !h.qt_present[h.comp[c].tq]) JFAIL(SNCAL_ERR_ARG, "missing quantisation table %d", h.comp[c].tq);
+        if (h.comp[c].td > 3 || h.comp[c].ta > 3 || !h.huff[0][h.comp[c].td].present || !h.huff[1][h.comp[c].ta].present)
+            JFAIL(SNCAL_ERR_ARG, "missing Huffman table");
+    }
+    h.mcus_x = (h.width + 8 * h.comp[0].h - 1) / (8 * h.comp[0].h);
+    h.mcus_y = (h.height + 8 * h.comp[0].v - 1) / (8 * h.comp[0].v);
+    for (int c = 0; c < h.ncomp; ++c) { h.bw[c] = h.mcus_x * h.comp[c].h; h.bh[c] = h.mcus_y * h.comp[c].v; }
+    return ok();
+}
+
+// ------------------------------------------------------------------------------------------------ host: entropy decode
+struct BitReader {                  // jdhuff.c jpeg_fill_bit_buffer: 0xFF00 -> 0xFF, zeros once a marker is reached
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0;
+    int n = 0;
+    inline void fill() {
+        while (n <= 56) {
+            unsigned b = 0;
+            if (p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    const unsigned nx = (p + 1 < end) ? p[1] : 0xD9;
+                    if (nx == 0) p += 2; else b = 0;
+                } else ++p;
+            }
+            acc = (acc << 8) | b;
+            n += 8;
+        }
+    }
+    inline unsigned peek16() { if (n < 16) fill(); return (unsigned)(acc >> (n - 16)) & 0xFFFFu; }
+    inline void skip(int k) { n -= k; }
+    inline int get(int k) { if (n < k) fill(); n -= k; return (int)((acc >> n) & ((1u << k) - 1)); }
+    bool restart(int expect) {
+        n = 0; acc = 0;
+        if (p + 1 >= end || p[0] != 0xFF || p[1] != 0xD0 + expect) return false;
+        p += 2;
+        return true;
+    }
+};
+
+inline int huff_decode(const Huff& t, BitReader& br) {
+    const unsigned c16 = br.peek16();
+    const unsigned f = t.fast[c16 >> 7];
+    if (f) { br.skip(f >> 8); return f & 255; }
+    int len = 10;
+    while (len <= 16 && (int)(c16 >> (16 - len)) > t.maxcode[len]) ++len;
+    if (len > 16) return -1;
+    br.skip(len);
+    return t.vals[(c16 >> (16 - len)) + t.valoff[len]];
+}
+inline int huff_extend(int r, int s) { return r < (1 << (s - 1)) ? r - (1 << s) + 1 : r; }
+
+// coefficients of every component, [comp][block_row][block_col][64], natural order; `coef` must be zeroed
+Fail entropy_decode(const Header& h, int16_t* coef) {
+    BitReader br{h.scan, h.end};
+    int pred[3] = {0, 0, 0};
+    int16_t* base[3];
+    size_t off = 0;
+    for (int c = 0; c < h.ncomp; ++c) { base[c] = coef + off; off += (size_t)h.bw[c] * h.bh[c] * 64; }
+    int rcount = 0, rnext = 0;
+    for (int my = 0; my < h.mcus_y; ++my)
+        for (int mx = 0; mx < h.mcus_x; ++mx) {
+            if (h.restart && rcount == h.restart) {
+                if (!br.restart(rnext)) JFAIL(SNCAL_ERR_ARG, "restart marker RST%d missing at MCU (%d,%d)", rnext, mx, my);
+                rnext = (rnext + 1) & 7;
+                rcount = 0;
+                pred[0] = pred[1] = pred[2] = 0;
+            }
+            ++rcount;
+            for (int c = 0; c < h.ncomp; ++c) {
+                const Huff& dc = h.huff[0][h.comp[c].td];
+                const Huff& ac = h.huff[1][h.comp[c].ta];
+                for (int by = 0; by < h.comp[c].v; ++by)
+                    for (int bx = 0; bx < h.comp[c].h; ++bx) {
+                        int16_t* blk = base[c] + ((size_t)(my * h.comp[c].v + by) * h.bw[c] + mx * h.comp[c].h + bx) * 64;
+                        int s = huff_decode(dc, br);
+                        if (s < 0 || s > 16) JFAIL(SNCAL_ERR_ARG, "corrupt Huffman data at MCU (%d,%d)", mx, my);
+                        if (s) pred[c] += huff_extend(br.get(s), s);
+                        blk[0] = (int16_t)pred[c];
+                        for (int k = 1; k < 64;) {
+                            const int rs = huff_decode(ac, br);
+                            if (rs < 0) JFAIL(SNCAL_ERR_ARG, "corrupt Huffman data at MCU (%d,%d)", mx, my);
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s) {
+                                k += r;
+                                if (k > 63) JFAIL(SNCAL_ERR_ARG, "coefficient index out of range at MCU (%d,%d)", mx, my);
+                                blk[kZigzag[k]] = (int16_t)huff_extend(br.get(s), s);
+                                ++k;
+                            } else if (r == 15) {
+                                k += 16;
+                            } else {
+                                break;
+                            }
+                        }
+                    }
+            }
+        }
+    return ok();
+}
+
+void fill_info(const Header& h, sncal_jpeg_info* info) {
+    info->width = h.width; info->height = h.height; info->components = h.ncomp;
+    info->h_samp = h.comp[0].h; info->v_samp = h.comp[0].v; info->restart_interval = h.restart;
+    for (int c = 0; c < 3; ++c) info->blocks[c] = c < h.ncomp ? h.bw[c] * h.bh[c] : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ device
+struct FrameDesc {
+    int32_t ncomp, hs, vs;
+    int32_t bw[3], bh[3];
+    uint32_t coef_off;              // first block of this frame in the batch coefficient buffer
+    uint16_t q[3][64];
+};
+
+constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+              F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+
+// one 8-point pass of jidctint.c jpeg_idct_islow (the same code serves columns and rows; only the descale differs)
+template <int SHIFT>
+__device__ __forceinline__ void idct8(const int (&x)[8], int (&o)[8]) {
+    int z2 = x[2], z3 = x[6];
+    int z1 = (z2 + z3) * F0_541;
+    int tmp2 = z1 + z3 * (-F1_847);
+    int tmp3 = z1 + z2 * F0_765;
+    z2 = x[0]; z3 = x[4];
+    int tmp0 = (z2 + z3) * 8192;
+    int tmp1 = (z2 - z3) * 8192;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = x[7]; tmp1 = x[5]; tmp2 = x[3]; tmp3 = x[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    constexpr int H = 1 << (SHIFT - 1);
+    o[0] = (tmp10 + tmp3 + H) >> SHIFT; o[7] = (tmp10 - tmp3 + H) >> SHIFT;
+    o[1] = (tmp11 + tmp2 + H) >> SHIFT; o[6] = (tmp11 - tmp2 + H) >> SHIFT;
+    o[2] = (tmp12 + tmp1 + H) >> SHIFT; o[5] = (tmp12 - tmp1 + H) >> SHIFT;
+    o[3] = (tmp13 + tmp0 + H) >> SHIFT; o[4] = (tmp13 - tmp0 + H) >> SHIFT;
+}
+
+// range_limit[(x) & RANGE_MASK] of jdmaster.c prepare_range_limit_table, centred on 128
+__device__ __forceinline__ unsigned range_limit(int x) {
+    const int v = x & 1023;
+    return v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896));
+}
+
+// planes: (B, 3, Hp, Wp) uint8, Hp/Wp = frame size rounded up to 16
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coef, const FrameDesc* __restrict__ desc,
+                                                        unsigned char* __restrict__ planes, int Hp, int Wp) {
+    __shared__ int ws[32][8][9];
+    const FrameDesc& fd = desc[blockIdx.y];
+    const int t = threadIdx.x, lb = t >> 3, i = t & 7;
+    int k = blockIdx.x * 32 + lb;                       // block index within the frame
+    const int n0 = fd.bw[0] * fd.bh[0], n1 = fd.ncomp > 1 ? fd.bw[1] * fd.bh[1] : 0;
+    const int total = n0 + (fd.ncomp > 1 ? 2 * n1 : 0);
+    const bool live = k < total;
+    int c = 0, kc = k;
+    if (kc >= n0) { kc -= n0; c = 1; if (kc >= n1) { kc -= n1; c = 2; } }
+    int o[8];
+    if (live) {
+        const int16_t* src = coef + ((size_t)fd.coef_off + k) * 64;
+        int x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (int)src[r * 8 + i] * (int)fd.q[c][r * 8 + i];
+        idct8<11>(x, o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[lb][r][i] = o[r];
+    }
+    __syncthreads();
+    if (!live) return;
+    int x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = ws[lb][i][j];
+    idct8<18>(x, o);
+    const int by = kc / fd.bw[c], bx = kc - by * fd.bw[c];
+    const unsigned lo = range_limit(o[0]) | (range_limit(o[1]) << 8) | (range_limit(o[2]) << 16) | (range_limit(o[3]) << 24);
+    const unsigned hi = range_limit(o[4]) | (range_limit(o[5]) << 8) | (range_limit(o[6]) << 16) | (range_limit(o[7]) << 24);
+    unsigned char* dst = planes + (((size_t)blockIdx.y * 3 + c) * Hp + by * 8 + i) * Wp + bx * 8;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// one chroma sample at full resolution: jdsample.c h2v2_fancy_upsample / h2v1_fancy_upsample / replication
+__device__ __forceinline__ int chroma_at(const unsigned char* __restrict__ p, int Wp, int x, int y, int hs, int vs, int cw, int ch) {
+    if (hs == 1) return p[(size_t)y * Wp + x];
+    const int c = x >> 1;
+    if (cw <= 2) return p[(size_t)(vs == 2 ? y >> 1 : y) * Wp + c];       // jinit_upsampler: fancy only when downsampled_width > 2
+    const int cn = (x & 1) ? min(c + 1, cw - 1) : max(c - 1, 0);
+    if (vs == 1) {
+        const unsigned char* row = p + (size_t)y * Wp;
+        return (3 * row[c] + row[cn] + ((x & 1) ? 2 : 1)) >> 2;
+    }
+    const int r = y >> 1;
+    const int rf = (y & 1) ? min(r + 1, ch - 1) : max(r - 1, 0);
+    const unsigned char* r0 = p + (size_t)r * Wp;
+    const unsigned char* r1 = p + (size_t)rf * Wp;
+    const int cs = 3 * r0[c] + r1[c], csn = 3 * r0[cn] + r1[cn];
+    return (3 * cs + csn + ((x & 1) ? 7 : 8)) >> 4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_colour_kernel(const unsigned char* __restrict__ planes, const FrameDesc* __restrict__ desc,
+                                                          unsigned char* __restrict__ bgr, int H, int W, int Hp, int Wp) {
+    const FrameDesc& fd = desc[blockIdx.y];
+    const int quads = (W + 3) >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= quads * H) return;
+    const int y = idx / quads, x0 = (idx - y * quads) * 4;
+    const unsigned char* py = planes + (size_t)blockIdx.y * 3 * Hp * Wp;
+    const unsigned char* pcb = py + (size_t)Hp * Wp;
+    const unsigned char* pcr = pcb + (size_t)Hp * Wp;
+    const int hs = fd.hs, vs = fd.vs, cw = (W + hs - 1) / hs, ch = (H + vs - 1) / vs;
+    unsigned char px[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = min(x0 + j, W - 1);
+        const int yy = py[(size_t)y * Wp + x];
+        int b = yy, g = yy, r = yy;
+        if (fd.ncomp == 3) {
+            const int xb = chroma_at(pcb, Wp, x, y, hs, vs, cw, ch) - 128;
+            const int xr = chroma_at(pcr, Wp, x, y, hs, vs, cw, ch) - 128;
+            r = clampi(yy + ((91881 * xr + 32768) >> 16), 0, 255);                     // jdcolor.c build_ycc_rgb_table
+            b = clampi(yy + ((116130 * xb + 32768) >> 16), 0, 255);
+            g = clampi(yy + ((-22554 * xb + 32768 - 46802 * xr) >> 16), 0, 255);
+        }
+        px[3 * j] = (unsigned char)b; px[3 * j + 1] = (unsigned char)g; px[3 * j + 2] = (unsigned char)r;
+    }
+    unsigned char* dst = bgr + ((size_t)blockIdx.y * H * W + (size_t)y * W + x0) * 3;
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0) {
+        unsigned* d32 = reinterpret_cast<unsigned*>(dst);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            d32[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | ((unsigned)px[4 * j + 3] << 24);
+    } else {
+        const int nb = 3 * min(4, W - x0);
+        for (int j = 0; j < nb; ++j) dst[j] = px[j];
+    }
+}
+
+size_t max_blocks(int H, int W) {                       // 4:4:4 rounded to 16-pixel MCUs bounds every supported layout
+    return (size_t)3 * ((H + 15) / 16 * 2) * ((W + 15) / 16 * 2);
+}
+
+}  // namespace
+
+struct sncal_jpeg {
+    int max_batch = 0, H = 0, W = 0, Hp = 0, Wp = 0, threads = 1;
+    size_t frame_blocks = 0;
+    int16_t* h_coef[2] = {nullptr, nullptr};
+    FrameDesc* h_desc[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    int16_t* d_coef = nullptr;
+    FrameDesc* d_desc = nullptr;
+    unsigned char* d_planes = nullptr;
+    int slot = 0;
+};
+
+extern "C" int sncal_jpeg_probe(const unsigned char* data, size_t len, sncal_jpeg_info* info) {
+    SNCAL_CHECK_ARG(data && info, "sncal_jpeg_probe: null argument");
+    Header h;
+    const Fail f = parse_header(data, len, h);
+    if (f.code != SNCAL_OK) { sncal::set_error("sncal_jpeg_probe: %s", f.msg.c_str()); return f.code; }
+    fill_info(h, info);
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_jpeg_entropy_decode(const unsigned char* data, size_t len, int16_t* coef, size_t cap,
+                                         sncal_jpeg_info* info) {
+    SNCAL_CHECK_ARG(data && coef && info, "sncal_jpeg_entropy_decode: null argument");
+    Header h;
+    Fail f = parse_header(data, len, h);
+    if (f.code != SNCAL_OK) { sncal::set_error("sncal_jpeg_entropy_decode: %s", f.msg.c_str()); return f.code; }
+    fill_info(h, info);
+    const size_t need = ((size_t)info->blocks[0] + info->blocks[1] + info->blocks[2]) * 64;
+    if (cap < need) { sncal::set_error("sncal_jpeg_entropy_decode: %zu coefficients needed, capacity %zu", need, cap); return SNCAL_ERR_WORKSPACE; }
+    memset(coef, 0, need * sizeof(int16_t));
+    f = entropy_decode(h, coef);
+    if (f.code != SNCAL_OK) { sncal::set_error("sncal_jpeg_entropy_decode: %s", f.msg.c_str()); return f.code; }
+    return SNCAL_OK;
+}
+
+extern "C" void sncal_jpeg_destroy(sncal_jpeg* d) {
+    if (!d) return;
+    for (int s = 0; s < 2; ++s) {
+        if (d->copied[s]) { (void)hipEventSynchronize(d->copied[s]); (void)hipEventDestroy(d->copied[s]); }
+        if (d->h_coef[s]) (void)hipHostFree(d->h_coef[s]);
+        if (d->h_desc[s]) (void)hipHostFree(d->h_desc[s]);
+    }
+    if (d->d_coef) (void)hipFree(d->d_coef);
+    if (d->d_desc) (void)hipFree(d->d_desc);
+    if (d->d_planes) (void)hipFree(d->d_planes);
+    delete d;
+}
+
+extern "C" int sncal_jpeg_create(int max_batch, int height, int width, int n_threads, sncal_jpeg** out) {
+    SNCAL_CHECK_ARG(out, "sncal_jpeg_create: null output");
+    *out = nullptr;
+    SNCAL_CHECK_ARG(max_batch > 0 && max_batch <= 4096, "sncal_jpeg_create: max_batch %d", max_batch);
+    SNCAL_CHECK_ARG(height > 0 && width > 0 && height <= 16384 && width <= 16384, "sncal_jpeg_create: frame size %dx%d", width, height);
+    SNCAL_CHECK_ARG(n_threads >= 0, "sncal_jpeg_create: n_threads %d", n_threads);
+    sncal_jpeg* d = new sncal_jpeg();
+    d->max_batch = max_batch; d->H = height; d->W = width;
+    d->Hp = (height + 15) / 16 * 16; d->Wp = (width + 15) / 16 * 16;
+    if (n_threads == 0) n_threads = (int)std::thread::hardware_concurrency();
+    d->threads = n_threads < 1 ? 1 : (n_threads > 32 ? 32 : n_threads);
+    d->frame_blocks = max_blocks(height, width);
+    const size_t coef_bytes = (size_t)max_batch * d->frame_blocks * 64 * sizeof(int16_t);
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&d->h_coef[s]), coef_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&d->h_desc[s]), (size_t)max_batch * sizeof(FrameDesc), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->copied[s], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_coef), coef_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_desc), (size_t)max_batch * sizeof(FrameDesc));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_planes), (size_t)max_batch * 3 * d->Hp * d->Wp);
+    if (e != hipSuccess) {
+        sncal::set_error("sncal_jpeg_create: allocation failed: %s", hipGetErrorString(e));
+        sncal_jpeg_destroy(d);
+        return SNCAL_ERR_HIP;
+    }
+    *out = d;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_jpeg_decode(sncal_jpeg* d, const unsigned char* const* data, const size_t* len, int B,
+                                 unsigned char* d_bgr, void* stream) {
+    SNCAL_CHECK_ARG(d, "sncal_jpeg_decode: null decoder");
+    SNCAL_CHECK_ARG(B >= 0 && B <= d->max_batch, "sncal_jpeg_decode: batch %d exceeds max_batch %d", B, d->max_batch);
+    if (B == 0) return SNCAL_OK;                                    // an empty batch is valid and touches nothing
+    SNCAL_CHECK_ARG(data && len && d_bgr, "sncal_jpeg_decode: null argument");
+    const int slot = d->slot;
+    d->slot ^= 1;
+    SNCAL_CHECK_HIP(hipEventSynchronize(d->copied[slot]));          // the copy that last used this staging slot
+    int16_t* h_coef = d->h_coef[slot];
+    FrameDesc* h_desc = d->h_desc[slot];
+    // pass 1 (serial, microseconds): headers -> block counts -> packed offsets
+    std::vector<Header> hdr(B);
+    size_t blocks = 0, max_frame = 0;
+    for (int b = 0; b < B; ++b) {
+        const Fail f = parse_header(data[b], len[b], hdr[b]);
+        if (f.code != SNCAL_OK) { sncal::set_error("sncal_jpeg_decode: frame %d: %s", b, f.msg.c_str()); return f.code; }
+        const Header& h = hdr[b];
+        SNCAL_CHECK_ARG(h.width == d->W && h.height == d->H, "sncal_jpeg_decode: frame %d is %dx%d, decoder was created for %dx%d",
+                        b, h.width, h.height, d->W, d->H);
+        FrameDesc& fd = h_desc[b];
+        memset(&fd, 0, sizeof(fd));
+        fd.ncomp = h.ncomp; fd.hs = h.comp[0].h; fd.vs = h.comp[0].v;
+        fd.coef_off = (uint32_t)blocks;
+        size_t nb = 0;
+        for (int c = 0; c < h.ncomp; ++c) {
+            fd.bw[c] = h.bw[c]; fd.bh[c] = h.bh[c];
+            memcpy(fd.q[c], h.qt[h.comp[c].tq], sizeof(fd.q[c]));
+            nb += (size_t)h.bw[c] * h.bh[c];
+        }
+        blocks += nb;
+        max_frame = nb > max_frame ? nb : max_frame;
+    }
+    // pass 2: Huffman decode, one frame per worker at a time
+    std::atomic<int> next{0}, bad{-1};
+    std::vector<Fail> fails(B);
+    auto work = [&]() {
+        for (int b; (b = next.fetch_add(1)) < B;) {
+            int16_t* dst = h_coef + (size_t)h_desc[b].coef_off * 64;
+            size_t nb = 0;
+            for (int c = 0; c < hdr[b].ncomp; ++c) nb += (size_t)hdr[b].bw[c] * hdr[b].bh[c];
+            memset(dst, 0, nb * 64 * sizeof(int16_t));
+            fails[b] = entropy_decode(hdr[b], dst);
+            if (fails[b].code != SNCAL_OK) { int exp = -1; bad.compare_exchange_strong(exp, b); }
+        }
+    };
+    const int nt = d->threads < B ? d->threads : B;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (bad.load() >= 0) {
+        int b = 0;
+        while (fails[b].code == SNCAL_OK) ++b;                      // report the first failing frame
+        sncal::set_error("sncal_jpeg_decode: frame %d: %s", b, fails[b].msg.c_str());
+        return fails[b].code;
+    }
+    hipStream_t st = sncal::as_stream(stream);
+    SNCAL_CHECK_HIP(hipMemcpyAsync(d->d_coef, h_coef, blocks * 64 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    SNCAL_CHECK_HIP(hipMemcpyAsync(d->d_desc, h_desc, (size_t)B * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+    SNCAL_CHECK_HIP(hipEventRecord(d->copied[slot], st));
+    jpeg_idct_kernel<<<dim3((unsigned)((max_frame + 31) / 32), B), 256, 0, st>>>(d->d_coef, d->d_desc, d->d_planes, d->Hp, d->Wp);
+    SNCAL_CHECK_LAUNCH();
+    const int quads = (d->W + 3) / 4;
+    jpeg_colour_kernel<<<dim3((unsigned)(((size_t)quads * d->H + 255) / 256), B), 256, 0, st>>>(d->d_planes, d->d_desc, d_bgr, d->H, d->W, d->Hp, d->Wp);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}

@@ -27,7 +27,8 @@ class CalibrationPipeline:
         self._pending = []
 
     def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False):
-        """frames (B,3,H,W) fp32 on the GPU.  Enqueues forward+decode on the current stream and the solve(s)
+        """frames (B,3,H,W) fp32 (ToTensor's output) or (B,H,W,3) uint8 BGR (cv2.imread's / JpegDecoder.decode's
+        output) on the GPU.  Enqueues forward+decode on the current stream and the solve(s)
         on the side stream; returns (kpts, records[, extra_records][, all_ranks_records]) device tensors
         (asynchronous).  gather=True (multi-GPU): the one collective of the path -- every rank's
         per-frame records to every rank -- is enqueued on the SIDE stream behind the solves, so the next batch's

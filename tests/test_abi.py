@@ -98,3 +98,47 @@ def test_file_interop_camera_json_and_lines_pickle(gold_dir, tmp_path):
         assert interop.load_lines_pickle(path) == per_image
     cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, lines_file=str(tmp_path / 'lines_True.pkl'))
     assert 15 in cc.lines_data['a.jpg']          # Middle line x Side line top (intersections.py:28)
+
+
+def test_jpeg_host_stage_matches_oracle_and_refuses_what_it_cannot_decode():
+    """N3 host half (no GPU): header parse + Huffman decode of libsncal equal the oracle's coefficient blocks on
+    every golden stream; unsupported / damaged input fails with the documented status and a message."""
+    import sncal_amd
+    from oracle import jpeg as oj
+    L = sncal_amd._lib
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'jpeg_cases.npz'))
+    names = [str(n) for n in g['names']] + ['full']
+    for n in names:
+        data = g['jpg.' + n].tobytes()
+        frame = oj.parse(data)
+        info = sncal_amd.jpeg.probe(data)
+        assert (info['width'], info['height'], info['components']) == (frame['width'], frame['height'], len(frame['comps']))
+        assert (info['h_samp'], info['v_samp']) == (frame['comps'][0]['h'], frame['comps'][0]['v'])
+        assert info['restart_interval'] == frame['restart']
+        want = oj.decode_coefficients(frame)
+        got = sncal_amd.jpeg.entropy_decode(data)
+        assert len(want) == len(got)
+        for a, b in zip(want, got):
+            assert a.shape == b.shape and np.array_equal(a, b), n
+
+    def status(data):
+        info = L.JpegInfo()
+        return L.lib().sncal_jpeg_probe(data, len(data), ctypes.byref(info))
+
+    assert status(g['jpg.progressive'].tobytes()) == -5                 # SNCAL_ERR_UNSUPPORTED
+    assert b'SOF2' in L.lib().sncal_last_error()
+    good = g['jpg.full'].tobytes()
+    assert status(good[:200]) == -1                                       # truncated inside the tables
+    assert status(b'\x89PNG\r\n\x1a\n' + good[8:]) == -1                  # not a JPEG
+    assert status(b'') == -1
+    # capacity check of the coefficient buffer
+    info = L.JpegInfo()
+    buf = np.zeros(64, np.int16)
+    assert L.lib().sncal_jpeg_entropy_decode(good, len(good), buf.ctypes.data, 64, ctypes.byref(info)) == -4
+    # a scan whose Huffman data is damaged: a code no table defines
+    sos = good.index(b'\xff\xda')
+    hdr_len = (good[sos + 2] << 8) | good[sos + 3]
+    broken = good[:sos + 2 + hdr_len] + b'\xff\x00' * 4000 + b'\xff\xd9'
+    big = np.zeros(sum(sncal_amd.jpeg.probe(good)['blocks']) * 64, np.int16)
+    st = L.lib().sncal_jpeg_entropy_decode(broken, len(broken), big.ctypes.data, big.size, ctypes.byref(info))
+    assert st == -1 and b'MCU' in L.lib().sncal_last_error()

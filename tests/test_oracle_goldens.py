@@ -130,3 +130,27 @@ def test_evaluator_oracle_matches_reference_capture(gold_dir):
                                               table=(pts, start))
         assert np.array_equal(c1, fr['conf1']) and np.array_equal(c2, fr['conf2']) and acc == max(fr['acc'])
     assert any(fr['acc'][1] > fr['acc'][0] for fr in frames)          # the mirrored pass wins somewhere
+
+
+def _jpeg_cases(gold_dir):
+    g = np.load(os.path.join(gold_dir, 'jpeg_cases.npz'))
+    return g, [str(n) for n in g['names']]
+
+
+def test_jpeg_oracle_matches_libjpeg_turbo_capture(gold_dir):
+    """N3: the decode restatement (Huffman, islow IDCT, fancy upsampling, fixed-point colour) reproduces, byte for
+    byte, what libjpeg-turbo decoded from the same streams -- every sampling layout, odd sizes down to 1x1, restart
+    intervals, three qualities; plus the 960x540 frame through row/column sums and a tile."""
+    from oracle import jpeg as oj
+    g, names = _jpeg_cases(gold_dir)
+    assert len(names) >= 70
+    for n in names:
+        got = oj.decode_bgr(g['jpg.' + n].tobytes())
+        assert got.dtype == np.uint8 and np.array_equal(got, g['bgr.' + n]), n
+    full = oj.decode_bgr(g['jpg.full'].tobytes())
+    assert full.shape == (540, 960, 3)
+    assert np.array_equal(full.astype(np.int64).sum(axis=(1, 2)), g['bgr.full.rowsum'])
+    assert np.array_equal(full.astype(np.int64).sum(axis=(0, 2)), g['bgr.full.colsum'])
+    assert np.array_equal(full[256:304, 448:512], g['bgr.full.tile'])
+    with pytest.raises(oj.JpegError):
+        oj.decode_bgr(g['jpg.progressive'].tobytes())

@@ -356,6 +356,74 @@ def gen_evaluator_batch():
     print('evaluator_batch ok:', n, 'frames; accuracies', [tuple(np.round(out[f"{i}.acc"], 3)) for i in range(n)])
 
 
+def jpeg_test_image(h, w, seed):
+    """A frame with what a broadcast frame has: smooth gradients (grass), sharp white lines, saturated patches
+    (range limiting / colour clamping), noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([40 + 30 * np.sin(xx / 37.0 + yy / 53.0), 130 + 60 * np.cos(xx / 29.0) * np.sin(yy / 41.0),
+                    50 + (xx * 3 + yy * 5) % 97], -1).astype(np.float64)
+    img += rng.normal(0, 5, img.shape)
+    for k in range(4):
+        img[np.abs(yy - (xx * (0.3 + 0.2 * k) + 5 * k)) < 1.2] = 255          # field lines
+    img[h // 3:h // 2, w // 4:w // 2] = [255, 0, 0]
+    img[h // 2:h // 2 + max(1, h // 6), w // 2:w // 2 + max(1, w // 5)] = [0, 0, 255]
+    img[: max(1, h // 8), : max(1, w // 8)] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def gen_jpeg():
+    """N3: JPEG byte streams (Pillow's encoder) and the pixels libjpeg-turbo decodes from them (Pillow's decoder,
+    library defaults JDCT_ISLOW + fancy upsampling = what cv2.imread of make_submit.py:62 runs), stored BGR as cv2
+    returns them.  cv2 itself is not installed in the build image."""
+    import io
+    from PIL import Image, features
+    assert features.check_feature('libjpeg_turbo')
+    out = {}
+    names = []
+    k = 0
+    for (h, w) in [(48, 64), (29, 37), (16, 16), (8, 8), (7, 5), (1, 1), (33, 3), (17, 4), (100, 130)]:
+        for sub in ('444', '422', '420', 'gray'):
+            for q, rs in ((95, 0), (60, 3), (20, 0)):
+                if q == 20 and (h, w) not in ((48, 64), (29, 37)):
+                    continue
+                im = Image.fromarray(jpeg_test_image(h, w, k))
+                kw = dict(quality=q)
+                if sub == 'gray':
+                    im = im.convert('L')
+                else:
+                    kw['subsampling'] = {'444': 0, '422': 1, '420': 2}[sub]
+                if rs:
+                    kw['restart_marker_blocks'] = rs
+                b = io.BytesIO()
+                im.save(b, 'JPEG', **kw)
+                data = b.getvalue()
+                ref = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))[..., ::-1]
+                name = f'{h}x{w}_{sub}_q{q}_r{rs}'
+                names.append(name)
+                out['jpg.' + name] = np.frombuffer(data, np.uint8)
+                out['bgr.' + name] = np.ascontiguousarray(ref)
+                k += 1
+    # one frame at the reference's size (C3: 960x540), 4:2:0 as video-frame extraction writes it
+    im = Image.fromarray(jpeg_test_image(540, 960, 1000))
+    b = io.BytesIO()
+    im.save(b, 'JPEG', quality=85, subsampling=2)
+    data = b.getvalue()
+    ref = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))[..., ::-1]
+    out['jpg.full'] = np.frombuffer(data, np.uint8)
+    out['bgr.full.rowsum'] = ref.astype(np.int64).sum(axis=(1, 2))
+    out['bgr.full.colsum'] = ref.astype(np.int64).sum(axis=(0, 2))
+    out['bgr.full.tile'] = np.ascontiguousarray(ref[256:304, 448:512])
+    # a progressive file: must be refused
+    b = io.BytesIO()
+    Image.fromarray(jpeg_test_image(32, 32, 5)).save(b, 'JPEG', quality=80, progressive=True)
+    out['jpg.progressive'] = np.frombuffer(b.getvalue(), np.uint8)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, 'jpeg_cases.npz'), **out)
+    print('jpeg ok:', len(names), 'cases,', os.path.getsize(os.path.join(GOLD, 'jpeg_cases.npz')) // 1024, 'KiB; full-size',
+          len(data), 'bytes')
+
+
 def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, batch=1):
     from oracle import hrnet_ref as hr, decode as od
     cfg = hr.load_config(cfg_name)
@@ -414,7 +482,7 @@ def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'hrnet']
+    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'jpeg', 'hrnet']
     if 'pitch' in which:
         gen_pitch()
     if 'decode' in which:
@@ -427,6 +495,8 @@ if __name__ == '__main__':
         gen_evaluator_batch()
     if 'evaluator' in which:
         gen_evaluator()
+    if 'jpeg' in which:
+        gen_jpeg()
     if 'hrnet' in which:
         gen_hrnet('hrnet_w18_64x96', 'hrnet_w18', (64, 96), 3, 4.0)
         gen_hrnet('hrnet_w18_135x240', 'hrnet_w18', (135, 240), 5, 4.0, store_full=False, batch=2)

@@ -217,6 +217,16 @@ int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const double* d_fi
                            const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
                            const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
                            float* d_out, void* stream);
+/* The same evaluation with the per-class outputs of evaluate_camera_prediction (evaluate_camera.py:172-226), both
+ * optional:  d_err (B,2,n_cls,max_gt) fp64 = `dict_errors`: distance of annotated point k to the predicted polyline
+ * of class c, [b][0] plain labels, [b][1] mirrored labels (the points come from class mirror[c]); NaN = no such
+ * point or class not predicted.  d_class_conf (B,2,n_cls,4) int32 = `per_class_confusion` entries
+ * {[0,0] points within the threshold, [0,1] points beyond it, [1,0] points of an annotated class that was not
+ * predicted, flag: class predicted but not annotated -- the reference books 2 (lines) or 9 (circles) at [0,1]}. */
+int sncal_evaluate_cameras_detail(const sncal_camera* d_cams, int B, const double* d_field, const int* d_class_start,
+                                  const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
+                                  const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
+                                  float* d_out, double* d_err, int* d_class_conf, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N3  input stage: JPEG bytes -> BGR uint8 frames on the device

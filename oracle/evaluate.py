@@ -207,24 +207,34 @@ def distance_to_polyline(point, polyline):
     return np.min(best)
 
 
-def evaluate_camera_prediction(projected, groundtruth, threshold):
-    """evaluate_camera.py:160-229 -> 2x2 float32 confusion [[TP, FP], [FN, 0]] over classes."""
+def evaluate_camera_prediction(projected, groundtruth, threshold, detail=False):
+    """evaluate_camera.py:160-229 -> 2x2 float32 confusion [[TP, FP], [FN, 0]] over classes; with detail=True also the
+    per-class point confusions ({class: 2x2}) and the per-class reprojection errors ({class: [distance per point]})."""
     conf = np.zeros((2, 2), dtype=np.float32)
+    per_class, errors = {}, {}
     det, gt = set(projected), set(groundtruth)
-    for _ in det - gt:
+    for c in det - gt:
+        per_class[c] = np.array([[0., 2. if "Circle" not in c else 9.], [0., 0.]])
         conf[0, 1] += 1
-    for _ in gt - det:
+    for c in gt - det:
+        per_class[c] = np.array([[0., 0.], [float(len(groundtruth[c])), 0.]])
         conf[1, 0] += 1
     for c in det & gt:
         ok = True
+        per_class[c] = np.zeros((2, 2))
         for point in groundtruth[c]:
-            if not distance_to_polyline(point, projected[c]) < threshold:
+            d = distance_to_polyline(point, projected[c])
+            if d < threshold:
+                per_class[c][0, 0] += 1
+            else:
+                per_class[c][0, 1] += 1
                 ok = False
+            errors.setdefault(c, []).append(d)
         if ok:
             conf[0, 0] += 1
         else:
             conf[0, 1] += 1
-    return conf
+    return (conf, per_class, errors) if detail else conf
 
 
 def mirror_labels(d):

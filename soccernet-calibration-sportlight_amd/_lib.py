@@ -77,6 +77,8 @@ SIGNATURES = {
                                            ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     'sncal_evaluate_cameras': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int,
                                               ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp]),
+    'sncal_evaluate_cameras_detail': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int,
+                                                     ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'sncal_lines_to_points': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, ctypes.c_double, vp, vp]),
     'sncal_hrnet_forward_u8': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
                                               ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),

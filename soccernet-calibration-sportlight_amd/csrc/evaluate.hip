@@ -87,18 +87,21 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const sncal_camera* __res
                                                        const int* __restrict__ mirror, int n_cls, int n_pts,
                                                        const double* __restrict__ gt, const int* __restrict__ gt_cnt,
                                                        const int* __restrict__ gt_extra, int max_gt, double threshold,
-                                                       int width, int height, double ppx, double ppy, float* __restrict__ out) {
+                                                       int width, int height, double ppx, double ppy, float* __restrict__ out,
+                                                       double* __restrict__ err, int* __restrict__ cls) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* const ex = reinterpret_cast<double*>(smem);                 // [n_pts] projected x
     double* const ey = ex + n_pts;                                      // [n_pts] projected y
     double* const poly = ey + n_pts;                                    // [2 * n_pts + 2 * n_cls] x 2
     int* const flags = reinterpret_cast<int*>(poly + 2 * (2 * n_pts + 2 * n_cls));     // [n_pts]: bit0 valid, bit1 inside
-    __shared__ int poly_n[EV_MAX_CLS], fail[2][EV_MAX_CLS];
+    __shared__ int poly_n[EV_MAX_CLS], fail[2][EV_MAX_CLS], npts[2][2][EV_MAX_CLS];   // npts[pass][below / not below][class]
     const int b = blockIdx.x, t = threadIdx.x;
     float* const o = out + (size_t)b * 12;
     const sncal_camera cam = cams[b];
     if (cam.status == 0) {                                              // no camera: a "missed" frame (completeness)
         if (t < 12) o[t] = 0.f;
+        if (err) for (int i = t; i < 2 * n_cls * max_gt; i += 256) err[(size_t)b * 2 * n_cls * max_gt + i] = NAN;
+        if (cls) for (int i = t; i < 2 * n_cls * 4; i += 256) cls[(size_t)b * 2 * n_cls * 4 + i] = 0;
         return;
     }
     for (int i = t; i < n_pts; i += 256) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const sncal_camera* __res
         }
         ex[i] = x; ey[i] = y; flags[i] = f;
     }
-    if (t < EV_MAX_CLS) { poly_n[t] = 0; fail[0][t] = 0; fail[1][t] = 0; }
+    if (t < EV_MAX_CLS) { poly_n[t] = 0; fail[0][t] = 0; fail[1][t] = 0; npts[0][0][t] = npts[0][1][t] = npts[1][0][t] = npts[1][1][t] = 0; }
     __syncthreads();
     if (t < n_cls) {                                                     // clipped polyline of class t, evaluate_camera.py:41-102
         const int s0 = class_start[t], s1 = class_start[t + 1];
@@ -148,12 +151,27 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const sncal_camera* __res
     for (int wi = t; wi < work; wi += 256) {
         const int k = wi % max_gt, c = (wi / max_gt) % n_cls, pass = wi / (max_gt * n_cls);
         const int gc = pass ? mirror[c] : c;
-        if (poly_n[c] == 0 || k >= gt_cnt[(size_t)b * n_cls + gc]) continue;
-        const double* g = gt + (((size_t)b * n_cls + gc) * max_gt + k) * 2;
-        const double d = dist_to_polyline(g[0], g[1], poly + 2 * (2 * class_start[c] + 2 * c), poly_n[c]);
-        if (!(d < threshold)) atomicOr(&fail[pass][c], 1);
+        double d = NAN;
+        if (poly_n[c] > 0 && k < gt_cnt[(size_t)b * n_cls + gc]) {
+            const double* g = gt + (((size_t)b * n_cls + gc) * max_gt + k) * 2;
+            d = dist_to_polyline(g[0], g[1], poly + 2 * (2 * class_start[c] + 2 * c), poly_n[c]);
+            const bool below = d < threshold;
+            if (!below) atomicOr(&fail[pass][c], 1);
+            atomicAdd(&npts[pass][below ? 0 : 1][c], 1);
+        }
+        if (err) err[(size_t)b * work + wi] = d;                         // dict_errors, evaluate_camera.py:216-219 (NaN = no such point)
     }
     __syncthreads();
+    if (cls && t < 2 * n_cls) {                                          // per_class_confusion, evaluate_camera.py:178-214
+        const int pass = t / n_cls, c = t - pass * n_cls, gc = pass ? mirror[c] : c;
+        const int ann = gt_cnt[(size_t)b * n_cls + gc];
+        const bool det = poly_n[c] > 0;
+        int* q = cls + (((size_t)b * 2 + pass) * n_cls + c) * 4;
+        q[0] = npts[pass][0][c];                                         // [0,0] annotated points within the threshold
+        q[1] = npts[pass][1][c];                                         // [0,1] ... beyond it
+        q[2] = (!det && ann > 0) ? ann : 0;                              // [1,0] points of a class that was not predicted
+        q[3] = (det && ann == 0) ? 1 : 0;                                // predicted, not annotated: the host books 2 (lines) or 9 (circles)
+    }
     if (t == 0) {
         float conf[2][4];
         float acc[2];
@@ -179,10 +197,10 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const sncal_camera* __res
 
 }  // namespace
 
-extern "C" int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const double* d_field, const int* d_class_start,
+extern "C" int sncal_evaluate_cameras_detail(const sncal_camera* d_cams, int B, const double* d_field, const int* d_class_start,
                                       const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
                                       const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
-                                      float* d_out, void* stream) {
+                                      float* d_out, double* d_err, int* d_class_conf, void* stream) {
     SNCAL_CHECK_ARG(B >= 0 && n_cls > 0 && n_cls <= EV_MAX_CLS && max_gt > 0, "sncal_evaluate_cameras: B=%d n_cls=%d max_gt=%d", B, n_cls, max_gt);
     if (B == 0) return SNCAL_OK;
     SNCAL_CHECK_ARG(d_cams && d_field && d_class_start && d_mirror && d_gt && d_gt_cnt && d_gt_extra && d_out, "sncal_evaluate_cameras: null pointer");
@@ -197,7 +215,15 @@ extern "C" int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const d
         attr_done = true;
     }
     hipLaunchKernelGGL(evaluate_kernel, dim3(B), dim3(256), lds, sncal::as_stream(stream), d_cams, B, d_field, d_class_start, d_mirror,
-                       n_cls, n_pts, d_gt, d_gt_cnt, d_gt_extra, max_gt, threshold, img_w, img_h, img_w / 2.0, img_h / 2.0, d_out);
+                       n_cls, n_pts, d_gt, d_gt_cnt, d_gt_extra, max_gt, threshold, img_w, img_h, img_w / 2.0, img_h / 2.0, d_out, d_err, d_class_conf);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
+}
+
+extern "C" int sncal_evaluate_cameras(const sncal_camera* d_cams, int B, const double* d_field, const int* d_class_start,
+                                      const int* d_mirror, int n_cls, const double* d_gt, const int* d_gt_cnt,
+                                      const int* d_gt_extra, int max_gt, double threshold, int img_w, int img_h,
+                                      float* d_out, void* stream) {
+    return sncal_evaluate_cameras_detail(d_cams, B, d_field, d_class_start, d_mirror, n_cls, d_gt, d_gt_cnt, d_gt_extra, max_gt,
+                                         threshold, img_w, img_h, d_out, nullptr, nullptr, stream);
 }

@@ -154,7 +154,10 @@ class CameraEvaluator:
                     gt[b, c, k] = (p['x'], p['y']) if isinstance(p, dict) else (p[0], p[1])
         return gt, cnt, extra, max_gt
 
-    def evaluate(self, records, annotations: Sequence[Dict[str, list]]):
+    def evaluate(self, records, annotations: Sequence[Dict[str, list]], detail: bool = False):
+        """-> out (B,12) fp32 [confusion plain, confusion mirrored, accuracy plain, accuracy mirrored, chosen pass,
+        evaluated]; with detail=True -> (out, err (B,2,C,max_gt) fp64, class_conf (B,2,C,4) int32), see
+        sncal_evaluate_cameras_detail and class_report()."""
         import torch
         _lib.require_device(records, torch.uint8, 'records')
         B = records.shape[0]
@@ -163,12 +166,64 @@ class CameraEvaluator:
         gt, cnt, extra, max_gt = self.pack(annotations)
         d_gt, d_cnt, d_extra = (torch.from_numpy(a).to(self.device) for a in (gt, cnt, extra))
         out = torch.empty((B, 12), dtype=torch.float32, device=self.device)
+        C = len(CLASSES)
+        err = torch.empty((B, 2, C, max_gt), dtype=torch.float64, device=self.device) if detail else None
+        cls = torch.empty((B, 2, C, 4), dtype=torch.int32, device=self.device) if detail else None
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().sncal_evaluate_cameras(records.data_ptr(), B, self._field.data_ptr(), self._start.data_ptr(),
-                                                         self._mirror.data_ptr(), len(CLASSES), d_gt.data_ptr(), d_cnt.data_ptr(),
-                                                         d_extra.data_ptr(), max_gt, self.threshold, self.width, self.height,
-                                                         out.data_ptr(), _lib.current_stream_ptr()), 'sncal_evaluate_cameras')
-        return out
+            _lib.check(_lib.lib().sncal_evaluate_cameras_detail(
+                records.data_ptr(), B, self._field.data_ptr(), self._start.data_ptr(), self._mirror.data_ptr(), C,
+                d_gt.data_ptr(), d_cnt.data_ptr(), d_extra.data_ptr(), max_gt, self.threshold, self.width, self.height,
+                out.data_ptr(), err.data_ptr() if detail else None, cls.data_ptr() if detail else None,
+                _lib.current_stream_ptr()), 'sncal_evaluate_cameras_detail')
+        return (out, err, cls) if detail else out
+
+    @staticmethod
+    def frame_detail(out, err, cls, annotations, b: int, which: int = 0):
+        """The `per_class_confusion` / `dict_errors` dictionaries evaluate_camera_prediction (evaluate_camera.py:172-226)
+        returns for frame b: which = 1 plain labels, 2 mirrored labels, 0 the pass evaluate_camera.py:303-311 keeps."""
+        o = out[b].detach().cpu().numpy() if hasattr(out, 'detach') else np.asarray(out[b])
+        p = (int(o[10]) if which == 0 else which) - 1
+        e = err[b, p].detach().cpu().numpy() if hasattr(err, 'detach') else np.asarray(err[b, p])
+        q = cls[b, p].detach().cpu().numpy() if hasattr(cls, 'detach') else np.asarray(cls[b, p])
+        per_class, errors = {}, {}
+        for c, name in enumerate(CLASSES):
+            below, beyond, missed, fp_flag = (int(v) for v in q[c])
+            if fp_flag:
+                per_class[name] = np.array([[0., 9. if 'Circle' in name else 2.], [0., 0.]])
+            elif missed:
+                per_class[name] = np.array([[0., 0.], [float(missed), 0.]])
+            elif below or beyond:
+                per_class[name] = np.array([[float(below), float(beyond)], [0., 0.]])
+                errors[name] = [float(v) for v in e[c, :below + beyond]]
+        for name, pts in annotations[b].items():                          # annotated classes the pitch model does not have
+            if name not in CLASSES and len(pts):
+                per_class[name] = np.array([[0., 0.], [float(len(pts)), 0.]])
+        return per_class, errors
+
+    @classmethod
+    def class_report(cls_, out, err, cls, annotations, bins: int = 30, hist_range=(0.0, 60.0)):
+        """evaluate_camera.py:335-373 over a batch: accumulated per-class confusion -> accuracy / precision / recall per
+        class, and the per-class reprojection-error histograms the script plots (counts, bin edges)."""
+        o = out.detach().cpu().numpy() if hasattr(out, 'detach') else np.asarray(out)
+        err = err.detach().cpu().numpy() if hasattr(err, 'detach') else np.asarray(err)
+        cls = cls.detach().cpu().numpy() if hasattr(cls, 'detach') else np.asarray(cls)
+        conf, errors = {}, {}
+        for b in range(len(o)):
+            if o[b, 11] <= 0:
+                continue
+            pc, er = cls_.frame_detail(o, err, cls, annotations, b)
+            for k, m in pc.items():
+                conf[k] = conf.get(k, 0) + m
+            for k, v in er.items():
+                errors.setdefault(k, []).extend(v)
+        report = {}
+        with np.errstate(divide='ignore', invalid='ignore'):
+            for k, m in conf.items():
+                report[k] = {'confusion': m, 'accuracy': float(m[0, 0] / m.sum()),
+                             'recall': float(np.float64(m[0, 0]) / (m[0, 0] + m[1, 0])),
+                             'precision': float(np.float64(m[0, 0]) / (m[0, 0] + m[0, 1]))}
+        hist = {k: np.histogram(np.asarray(v)[np.isfinite(v)], bins=bins, range=hist_range) for k, v in errors.items()}
+        return report, errors, hist
 
     @staticmethod
     def summarize(out) -> Dict[str, float]:

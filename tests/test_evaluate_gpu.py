@@ -55,6 +55,46 @@ def test_evaluator_matches_reference_capture(sncal, cuda, gold_dir):
     assert abs(s['completeness'] - 10 / 11) < 1e-12 and 0 < s['accuracy'] < 1 and abs(s['final_score'] - s['completeness'] * s['accuracy']) < 1e-12
 
 
+def test_per_class_confusions_and_errors_match_reference_capture(sncal, cuda, gold_dir):
+    """sncal_evaluate_cameras_detail: `per_class_confusion` exactly and `dict_errors` (fp64 distances) to 1e-9 relative
+    against what evaluate_camera_prediction returned in the reference, both label orientations; class_report
+    accumulates them as evaluate_camera.py:335-373 does."""
+    g, frames = _eval_frames(gold_dir)
+    ev = sncal.CameraEvaluator(cuda, 960, 540, threshold=5)
+    frames_m = frames[:3] + [None] + frames[3:]
+    ann = [fr['gt'] if fr is not None else {} for fr in frames_m]
+    out, err, cls = ev.evaluate(_records(sncal, frames_m, cuda), ann, detail=True)
+    assert torch.isnan(err[3]).all() and not cls[3].any()
+    plain = ev.evaluate(_records(sncal, frames_m, cuda), ann)
+    assert torch.equal(plain, out)
+    n_err = 0
+    for i, fr in enumerate(frames_m):
+        if fr is None:
+            continue
+        for which in (1, 2):
+            pc, er = ev.frame_detail(out, err, cls, ann, i, which)
+            want_pc, want_er = fr[f'pc{which}'], fr[f'err{which}']
+            assert set(pc) == set(want_pc) and set(er) == set(want_er), (i, which)
+            for k in pc:
+                assert np.array_equal(pc[k], want_pc[k]), (i, which, k)
+            for k in er:
+                assert np.allclose(er[k], want_er[k], rtol=1e-9, atol=1e-9), (i, which, k)
+                n_err += len(er[k])
+    assert n_err > 200
+    report, errors, hist = ev.class_report(out, err, cls, ann)
+    acc_conf = {}
+    for i, fr in enumerate(frames_m):
+        if fr is None:
+            continue
+        which = 1 if fr['acc'][0] > fr['acc'][1] else 2
+        for k, m in fr[f'pc{which}'].items():
+            acc_conf[k] = acc_conf.get(k, 0) + m
+    assert set(report) == set(acc_conf)
+    for k in report:
+        assert np.array_equal(report[k]['confusion'], acc_conf[k])
+        assert sum(hist[k][0]) <= len(errors[k]) if k in hist else True
+
+
 def test_evaluator_matches_oracle_on_random_cameras(sncal, cuda):
     """64 synthetic cameras (synth.sample_camera) with perturbed predictions and subsampled annotations."""
     rng = np.random.default_rng(3)

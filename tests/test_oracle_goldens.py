@@ -111,8 +111,12 @@ def _eval_frames(gold_dir):
     frames = []
     for i in range(int(g['n'])):
         gt = {str(c): [tuple(p) for p in g[f'{i}.gt.{c}']] for c in g[f'{i}.gt_classes']}
+        detail = {}
+        for tag in ('1', '2'):
+            detail['pc' + tag] = {str(c): g[f'{i}.pc{tag}.{c}'] for c in g[f'{i}.pc{tag}.classes']}
+            detail['err' + tag] = {str(c): g[f'{i}.err{tag}.{c}'] for c in g[f'{i}.err{tag}.classes']}
         frames.append(dict(position=g[f'{i}.position'], rotation=g[f'{i}.rotation'], f=g[f'{i}.f'], pp=g[f'{i}.pp'], gt=gt,
-                           conf1=g[f'{i}.conf1'], conf2=g[f'{i}.conf2'], acc=g[f'{i}.acc'], npoly=g[f'{i}.npoly']))
+                           conf1=g[f'{i}.conf1'], conf2=g[f'{i}.conf2'], acc=g[f'{i}.acc'], npoly=g[f'{i}.npoly'], **detail))
     return g, frames
 
 
@@ -129,6 +133,11 @@ def test_evaluator_oracle_matches_reference_capture(gold_dir):
         conf, acc, c1, c2 = oe.evaluate_frame(fr['position'], fr['rotation'], fr['f'][0], fr['f'][1], tuple(fr['pp']), fr['gt'], 5,
                                               table=(pts, start))
         assert np.array_equal(c1, fr['conf1']) and np.array_equal(c2, fr['conf2']) and acc == max(fr['acc'])
+        for tag, labels in (('1', fr['gt']), ('2', oe.mirror_labels(fr['gt']))):      # per-class confusions and errors
+            _, pc, er = oe.evaluate_camera_prediction(poly, labels, 5, detail=True)
+            assert set(pc) == set(fr['pc' + tag]) and set(er) == set(fr['err' + tag])
+            assert all(np.array_equal(pc[k], fr['pc' + tag][k]) for k in pc)
+            assert all(np.array_equal(np.array(er[k]), fr['err' + tag][k]) for k in er)
     assert any(fr['acc'][1] > fr['acc'][0] for fr in frames)          # the mirrored pass wins somewhere
 
 

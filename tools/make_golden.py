@@ -325,8 +325,8 @@ def gen_evaluator_batch():
         if seed == 7:
             gt = mirror_labels(gt)                                   # left/right swapped annotation: the mirrored pass wins
         poly_pred = get_polylines(js_pred, 960, 540, sampling_factor=0.9)
-        c1, _, _ = evaluate_camera_prediction(poly_pred, gt, 5)
-        c2, _, _ = evaluate_camera_prediction(poly_pred, mirror_labels(gt), 5)
+        c1, pc1, er1 = evaluate_camera_prediction(poly_pred, gt, 5)
+        c2, pc2, er2 = evaluate_camera_prediction(poly_pred, mirror_labels(gt), 5)
         a1 = c1[0, 0] / c1.sum() if c1.sum() > 0 else 0.
         a2 = c2[0, 0] / c2.sum() if c2.sum() > 0 else 0.
         # the oracle on the same camera / annotations
@@ -342,6 +342,18 @@ def gen_evaluator_batch():
         oc, oa, o1, o2 = oe.evaluate_frame(pos, R, js_pred['x_focal_length'], js_pred['y_focal_length'],
                                            tuple(js_pred['principal_point']), gt_t, 5)
         assert np.array_equal(o1, c1) and np.array_equal(o2, c2) and oa == max(a1, a2), (o1, c1, o2, c2)
+        # per-class point confusions and reprojection errors (evaluate_camera.py:172-226), both label orientations
+        for tag, labels, pc_ref, er_ref in (('1', gt_t, pc1, er1), ('2', oe.mirror_labels(gt_t), pc2, er2)):
+            _, pc_o, er_o = oe.evaluate_camera_prediction(mine, labels, 5, detail=True)
+            assert set(pc_o) == set(pc_ref) and set(er_o) == set(er_ref)
+            for k in pc_ref:
+                assert np.array_equal(pc_o[k], pc_ref[k]), k
+                out[f'{n}.pc{tag}.{k}'] = np.asarray(pc_ref[k], dtype=np.float64)
+            for k in er_ref:
+                assert np.array_equal(np.array(er_o[k]), np.array(er_ref[k])), k
+                out[f'{n}.err{tag}.{k}'] = np.array(er_ref[k], dtype=np.float64)
+            out[f'{n}.pc{tag}.classes'] = np.array(sorted(pc_ref))
+            out[f'{n}.err{tag}.classes'] = np.array(sorted(er_ref))
         out[f'{n}.position'] = pos; out[f'{n}.rotation'] = R
         out[f'{n}.f'] = np.array([js_pred['x_focal_length'], js_pred['y_focal_length']])
         out[f'{n}.pp'] = np.array(js_pred['principal_point'])

@@ -1,0 +1,100 @@
+"""Harness counterpart of /root/reference/src/utils/make_submit.py:42-75: image directory ->
+`camera_<frame>.json` files + completeness, with every stage of the loop on the GPU path.
+
+    reference loop (per batch of 8)                      here (per batch, default 64)
+    cv2.imread + ToTensor + torch.stack   :62-63          JpegDecoder.decode (host Huffman, device IDCT/colour) -> uint8 BGR
+    model.predict(tensor).cpu().numpy()   :64             CalibrationPipeline.submit: forward + decode on the main stream,
+    16-process pool, CameraCreator per row :65-69          one batched solve on a side stream (overlaps the next batch)
+    json.dump(cam.to_json_parameters())   :36-37          interop.save_cameras, written while the next batch runs
+
+    python -m sncal_amd.submit --img-dir DIR --model model.pth --save-dir OUT [--lines-file lines.pkl]
+"""
+import argparse
+import os
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .interop import save_cameras
+from .jpeg import JpegDecoder, probe
+from .metamodel import load_model
+from .pipeline import CalibrationPipeline
+from .pitch import PITCH_POINTS
+from .prediction import CameraCreator, camera_from_record
+
+
+def default_calibrator(lines_file: Optional[str] = None) -> CameraCreator:
+    """The CameraCreator make_submit.py:45-50 builds."""
+    return CameraCreator(PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter',
+                         lines_file=lines_file, max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0,
+                         min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
+
+
+def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, batch_size: int = 64,
+                decoder_threads: int = 0, img_names: Optional[List[str]] = None) -> dict:
+    """Returns {'frames', 'written', 'completeness'} (make_submit.py:72 prints the last)."""
+    os.makedirs(save_dir, exist_ok=True)
+    if img_names is None:
+        img_names = [n for n in os.listdir(img_dir) if n.endswith('.jpg')]          # make_submit.py:56
+    total = len(img_names)
+    if total == 0:
+        return {'frames': 0, 'written': 0, 'completeness': 0.0}
+    with open(os.path.join(img_dir, img_names[0]), 'rb') as f:
+        info = probe(f.read())
+    H, W = info['height'], info['width']
+    net = model.nn_module
+    pt = model.prediction_transform
+    pipe = CalibrationPipeline(net, calibrator, decode_size=(pt.H, pt.W))
+    dec = JpegDecoder(H, W, max_batch=batch_size, threads=decoder_threads, device=net.device)
+    frames = [torch.empty((batch_size, H, W, 3), dtype=torch.uint8, device=net.device) for _ in range(2)]
+    pending = []                                                                    # (names, records, event)
+    written = 0
+
+    def drain(keep: int):
+        nonlocal written
+        while len(pending) > keep:
+            names, rec, ev = pending.pop(0)
+            ev.synchronize()
+            cams = [camera_from_record(r, calibrator.img_size) for r in calibrator.records(rec)]
+            written += save_cameras(cams, names, save_dir)
+
+    for k, i in enumerate(range(0, total, batch_size)):
+        names = img_names[i:i + batch_size]
+        blobs = []
+        for n in names:
+            with open(os.path.join(img_dir, n), 'rb') as f:
+                blobs.append(f.read())
+        x = dec.decode(blobs, frames[k & 1][:len(blobs)])
+        out = pipe.submit(x, names=names)
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(pipe.solve_stream):
+            ev.record(pipe.solve_stream)
+        pending.append((names, out[1], ev))
+        drain(1)                                                                    # write batch k-1 while batch k runs
+    drain(0)
+    pipe.join()
+    dec.close()
+    return {'frames': total, 'written': written, 'completeness': written / total}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='Camera calibration of a directory of frames (make_submit.py counterpart)')
+    ap.add_argument('--img-dir', required=True)
+    ap.add_argument('--model', required=True, help='argus checkpoint of the keypoint model (model_name/params/nn_state_dict)')
+    ap.add_argument('--save-dir', required=True)
+    ap.add_argument('--lines-file', default=None, help='lines pickle of export_line_result.py (optional)')
+    ap.add_argument('--batch-size', type=int, default=64)
+    ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    a = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise _lib.SncalError('no GPU visible: this package has no CPU path')
+    model = load_model(a.model, loss=None, optimizer=None, device=a.device, dtype=a.dtype)
+    res = make_submit(a.img_dir, model, default_calibrator(a.lines_file), a.save_dir, batch_size=a.batch_size)
+    print(f"Completeness: {res['completeness']:.2f}")
+    return res
+
+
+if __name__ == '__main__':
+    main()

@@ -85,3 +85,34 @@ def test_bad_frames_fail_loudly_and_name_the_frame(sncal, cuda, gold_dir):
     out = dec.decode([good])                            # still usable after the failures
     assert np.array_equal(out[0].cpu().numpy(), g['bgr.48x64_420_q95_r0'])
     dec.close()
+
+
+def test_directory_harness_runs_the_make_submit_loop(sncal, cuda, gold_dir, tmp_path):
+    """make_submit.py:42-75 counterpart: JPEG files -> JpegDecoder -> predict -> batched solve -> camera_<frame>.json.
+    Five frames in batches of two (a ragged last batch); the keypoints the loop solved from are those of the
+    reference-shaped path (decoded pixels -> ToTensor -> model.predict), and the files written are exactly the
+    cameras CameraCreator returns for them."""
+    g, _ = _cases(gold_dir)
+    full = g['jpg.full'].tobytes()
+    img_dir, save_dir = tmp_path / 'imgs', tmp_path / 'out'
+    img_dir.mkdir()
+    names = [f'{i:05d}.jpg' for i in range(5)]
+    for n in names:
+        (img_dir / n).write_bytes(full)
+    (img_dir / 'notes.txt').write_text('not a frame')
+    cfg = hr.load_config('hrnet_w18')
+    ck = {'model_name': 'HRNetMetaModel',
+          'params': {'nn_module': {'hrnet_config': cfg, 'num_refinement_stages': 0, 'num_heatmaps': 58},
+                     'prediction_transform': {'size': [540, 960]}, 'device': 'cuda:0'},
+          'nn_state_dict': hr.seeded_state_dict(cfg, 3, 4.0)}
+    path = str(tmp_path / 'model.pth')
+    torch.save(ck, path)
+    model = sncal.load_model(path, loss=None, optimizer=None, device='cuda:0', dtype='fp32')
+    cal = sncal.submit.default_calibrator()
+    res = sncal.submit.make_submit(str(img_dir), model, cal, str(save_dir), batch_size=2, decoder_threads=2)
+    assert res['frames'] == 5 and 0.0 <= res['completeness'] <= 1.0
+    x = torch.from_numpy(np.ascontiguousarray(oj.decode_bgr(full))).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    pred = model.predict(torch.stack([x] * 5))
+    cams = cal.solve_batch(pred.cpu().numpy(), names)
+    want = sorted('camera_' + n.replace('.jpg', '.json') for n, c in zip(names, cams) if c is not None)
+    assert sorted(os.listdir(save_dir)) == want and res['written'] == len(want)

@@ -23,7 +23,7 @@ def pack_records(kpts: torch.Tensor, *records: torch.Tensor) -> torch.Tensor:
 def gather_records(local: torch.Tensor, counts=None) -> torch.Tensor:
     """One collective: every rank receives the records of all frames, in frame order.
     `local` (b_r, bytes) uint8; ranks may hold different frame counts (`counts` = list per rank)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size()
     if counts is None:

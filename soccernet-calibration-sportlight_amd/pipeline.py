@@ -3,6 +3,11 @@
 make_submit pushes each prediction row to a 16-process CPU pool; here the network runs on the caller's
 stream and the batched camera solve runs on a side stream, ordered by events, so the solve of batch i
 overlaps the convolutions of batch i+1 (the solve is latency-bound and only occupies 64 wavefronts).
+
+Streams only overlap when they sit on different hardware queues: HIP maps streams onto GPU_MAX_HW_QUEUES (default
+4) queues, and with the multi-GPU gather a third stream (RCCL's) joins; measured, it then aliases the network
+stream and the step grows from 43 to 54 ms.  Export GPU_MAX_HW_QUEUES=8 before the process touches the GPU
+(bench.py and submit.py do).
 """
 import torch
 

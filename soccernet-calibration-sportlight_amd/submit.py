@@ -13,7 +13,9 @@ import argparse
 import os
 from typing import List, Optional
 
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # see pipeline.py: streams must not alias on a hardware queue
+
+import torch  # noqa: E402
 
 from . import _lib
 from .interop import save_cameras

@@ -101,6 +101,10 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lanes', type=int, default=1,
+                    help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md 5: '
+                         '2 lanes fill kernel tails and launch gaps, +7 %% frames/s, but per-kernel HIP-event durations then '
+                         'measure a shared GPU, so the roofline object is only meaningful at 1)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -122,9 +126,15 @@ def main():
     import sncal_amd
     cfg_name = 'hrnet_w48'
     sd = seeded_weights(cfg_name, seed=1)
-    net = sncal_amd.HRNetHeatmap(cfg_name, dtype=args.dtype, device=dev)
-    net.load_state_dict(sd)
     B = args.batch
+    L = max(1, args.lanes)
+    if B % L:
+        raise SystemExit(f'--batch {B} is not a multiple of --lanes {L}')
+    nets = []
+    for _ in range(L):
+        net = sncal_amd.HRNetHeatmap(cfg_name, dtype=args.dtype, device=dev)
+        net.load_state_dict(sd)
+        nets.append(net)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     x = torch.rand((B, 3, 540, 960), device=dev, generator=gen)          # synthetic frames, resident in HBM
@@ -133,7 +143,11 @@ def main():
                                  algorithm='iterative_voter', lines_file=None, max_rmse=55.0, max_rmse_rel=5.0,
                                  min_points=5, min_focal_length=10.0, min_points_per_plane=6,
                                  min_points_for_refinement=6, reliable_thresh=57)
-    pipe = sncal_amd.CalibrationPipeline(net, cc, decode_size=(540, 960))
+    pipes = [sncal_amd.CalibrationPipeline(n, cc, decode_size=(540, 960)) for n in nets]
+    lane_streams = [None] if L == 1 else [torch.cuda.Stream(device=dev) for _ in range(L)]
+    bl = B // L
+    xs = [x[i * bl:(i + 1) * bl] for i in range(L)]
+    kps = [kp_synth[i * bl:(i + 1) * bl].contiguous() for i in range(L)]
     last = {}
 
     def step():
@@ -141,12 +155,21 @@ def main():
         # step's convolutions); every solve is complete before the closing fence of the timed region
         # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on
         # the side stream behind the solves
-        out = pipe.submit(x, extra_keypoints=kp_synth, gather=use_dist)
-        last['rec_syn'] = out[2]
-        return out[0]
+        for i in range(L):
+            if lane_streams[i] is None:
+                out = pipes[i].submit(xs[i], extra_keypoints=kps[i], gather=use_dist)
+            else:
+                with torch.cuda.stream(lane_streams[i]):
+                    out = pipes[i].submit(xs[i], extra_keypoints=kps[i], gather=use_dist)
+            last[i] = out[2]
 
     def fence():
-        pipe.join()
+        for i in range(L):
+            if lane_streams[i] is None:
+                pipes[i].join()
+            else:
+                with torch.cuda.stream(lane_streams[i]):
+                    pipes[i].join()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -154,7 +177,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    net.set_profiling(True)
+    for n in nets:
+        n.set_profiling(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     solve_ms = 0.0
     t0 = time.perf_counter()
@@ -162,11 +186,17 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = net.get_profile()
-    net.set_profiling(False)
+    merged = {}
+    for n in nets:
+        for q in n.get_profile():
+            m = merged.setdefault(q['kernel'], dict(q, ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            for k in ('ms', 'launches', 'flops', 'bytes'):
+                m[k] += q[k]
+        n.set_profiling(False)
+    prof = list(merged.values())
     # solve-stage time, measured separately after the timed region (torch events see torch's current stream,
     # which is the stream libsncal launches on)
-    rec_syn = last['rec_syn']
+    rec_syn = cc.solve_device(kp_synth)
     ev[0].record()
     for _ in range(3):
         cc.solve_device(kp_synth, out=rec_syn)
@@ -199,7 +229,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (uniform-noise frames, random-init HRNet-W48; solve also driven by projected-template keypoints)',
             'config': {'workload': 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter)',
-                       'frames_per_gpu': B, 'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
+                       'frames_per_gpu': B, 'lanes': L, 'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
                        'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}',
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * FLOP_PER_FRAME / 1e12, 1),
                        'kernel_time_share': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(prof, key=lambda q: -q['ms'])[:8]}},

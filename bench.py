@@ -149,6 +149,8 @@ def main():
     xs = [x[i * bl:(i + 1) * bl] for i in range(L)]
     kps = [kp_synth[i * bl:(i + 1) * bl].contiguous() for i in range(L)]
     last = {}
+    diag_nosolve = os.environ.get('SNCAL_BENCH_DIAG') == 'nosolve'
+    diag_noprof = os.environ.get('SNCAL_BENCH_DIAG') == 'noprof'
 
     def step():
         # forward + decode on the main stream; both solves on the pipeline's side stream (they overlap the next
@@ -156,6 +158,9 @@ def main():
         # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on
         # the side stream behind the solves
         for i in range(L):
+            if diag_nosolve:                             # diagnosis only: network + decode, no solves (not a valid bench line)
+                nets[i].forward(xs[i], want_heat=False, decode_size=(540, 960))
+                continue
             if lane_streams[i] is None:
                 out = pipes[i].submit(xs[i], extra_keypoints=kps[i], gather=use_dist)
             else:
@@ -178,7 +183,7 @@ def main():
         step()
     fence()
     for n in nets:
-        n.set_profiling(True)
+        n.set_profiling(not diag_noprof)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     solve_ms = 0.0
     t0 = time.perf_counter()
@@ -194,6 +199,9 @@ def main():
                 m[k] += q[k]
         n.set_profiling(False)
     prof = list(merged.values())
+    if os.environ.get('SNCAL_BENCH_DIAG'):               # diagnosis runs print the step time only
+        print('diag', os.environ['SNCAL_BENCH_DIAG'], round(dt / args.steps * 1e3, 3), 'ms/step')
+        return
     # solve-stage time, measured separately after the timed region (torch events see torch's current stream,
     # which is the stream libsncal launches on)
     rec_syn = cc.solve_device(kp_synth)

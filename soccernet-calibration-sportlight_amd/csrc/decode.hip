@@ -14,7 +14,10 @@
 // around the first peak, second flat argmax.  One workgroup per (b,c) plane, two sweeps (the second
 // one is served by L2: a 135x240 plane is 130 KB).
 #include "common.hpp"
+#include "ops.hpp"
+#include "softmax_px.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -135,6 +138,102 @@ __global__ __launch_bounds__(256) void kp_decode_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused log-softmax + D1 decode for callers that do not want the heatmap (predict() / the pipeline): the
+// (B,C,h,w) fp32 log-probabilities -- 30 MB per frame at 270x480 -- are never written or re-read.
+//   pass 1  logsoftmax_rowcol_kernel  one workgroup per (strip of RS rows, frame): per 64-pixel tile the same
+//           per-pixel channel softmax as softmax_nchw_kernel (softmax_px.hpp: bit-identical values), transposed
+//           through LDS; a thread then owns (channel, 16 pixels): per-column maxima over the strip stay in registers,
+//           per-row maxima accumulate in LDS.  Writes row maxima (B,C-1,h) and per-strip column maxima
+//           (B,strips,C-1,w): 3 % of the heatmap's bytes.
+//   pass 2  kp_finish_kernel          one workgroup per (b,c): column maxima over strips, then exactly the
+//           first-occurrence-after-exp rule of kp_decode_kernel.
+// max is exact in any grouping, so the keypoints equal softmax_nchw_kernel -> kp_decode_kernel bit for bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RC_ROWS = 18;      // rows per strip: 6 / 9 cost more in partials, 30 / 45 leave too few workgroups (0.65 ms at 18 vs 0.72-0.89)
+
+__global__ __launch_bounds__(256) void logsoftmax_rowcol_kernel(const float* __restrict__ logits, int cstride, int C, int h, int w,
+                                                                float* __restrict__ rowmax, float* __restrict__ colpart, int nstrips) {
+    __shared__ float s_t[64][65];
+    __shared__ float s_rm[4][64];
+    __shared__ float s_row[RC_ROWS][64];
+    const int t = threadIdx.x, px = t >> 2, q = t & 3;
+    const int c = t & 63, qq = t >> 6;
+    const int strip = blockIdx.x, b = blockIdx.y;
+    const int y0 = strip * RC_ROWS, rows = min(RC_ROWS, h - y0);
+    const int C1 = C - 1;
+    for (int i = t; i < RC_ROWS * 64; i += 256) s_row[i >> 6][i & 63] = -INFINITY;
+    const float* img = logits + (size_t)b * h * w * cstride;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        float cm[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cm[i] = -INFINITY;
+        const bool live = x0 + px < w;
+        float v[16];
+        sncal::load_px16(img, (size_t)y0 * w + x0 + px, cstride, C, q, live, v);
+        for (int yl = 0; yl < rows; ++yl) {
+            float r[16], vn[16];
+            const bool more = yl + 1 < rows;                   // next row's pixel: in flight under this row's arithmetic
+            sncal::load_px16(img, (size_t)(y0 + yl + (more ? 1 : 0)) * w + x0 + px, cstride, C, q, live && more, vn);
+            sncal::softmax_px16(v, q, C, 1, r);
+            __syncthreads();                                   // previous tile's readers are done with s_t / s_rm
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s_t[q * 16 + j][px] = live ? r[j] : -INFINITY;
+            __syncthreads();
+            float rm = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float u = s_t[c][qq * 16 + i];
+                cm[i] = fmaxf(cm[i], u);
+                rm = fmaxf(rm, u);
+            }
+            s_rm[qq][c] = rm;
+            __syncthreads();
+            if (t < 64) s_row[yl][t] = fmaxf(s_row[yl][t], fmaxf(fmaxf(s_rm[0][t], s_rm[1][t]), fmaxf(s_rm[2][t], s_rm[3][t])));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = vn[j];
+        }
+        if (c < C1) {
+            float* dst = colpart + (((size_t)b * nstrips + strip) * C1 + c) * w + x0 + qq * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (x0 + qq * 16 + i < w) dst[i] = cm[i];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < rows * C1; i += 256) {
+        const int cc = i / rows, yl = i - cc * rows;
+        rowmax[((size_t)b * C1 + cc) * h + y0 + yl] = s_row[yl][cc];
+    }
+}
+
+__global__ __launch_bounds__(256) void kp_finish_kernel(const float* __restrict__ rowmax, const float* __restrict__ colpart, int nstrips,
+                                                        int C1, int h, int w, int img_h, int img_w, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_row = smem;                          // [h]
+    float* s_col = smem + h;                      // [w]
+    float* s_scr = s_col + w;                     // [4]
+    const int plane = blockIdx.x, b = plane / C1, c = plane - b * C1;
+    for (int y = threadIdx.x; y < h; y += 256) s_row[y] = rowmax[(size_t)plane * h + y];
+    for (int x = threadIdx.x; x < w; x += 256) {
+        float m = -INFINITY;
+        for (int s = 0; s < nstrips; ++s) m = fmaxf(m, colpart[(((size_t)b * nstrips + s) * C1 + c) * w + x]);
+        s_col[x] = m;
+    }
+    __syncthreads();
+    int xi, yi;
+    float xp, yp;
+    first_max_after_exp(s_col, w, s_scr, &xi, &xp);
+    __syncthreads();
+    first_max_after_exp(s_row, h, s_scr, &yi, &yp);
+    if (threadIdx.x == 0) {
+        float* o = out + (size_t)plane * 3;
+        o[0] = (float)((long long)xi * img_w) / (float)w;
+        o[1] = (float)((long long)yi * img_h) / (float)h;
+        o[2] = fminf(xp, yp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // L2 line decode
 // ---------------------------------------------------------------------------------------------
 struct Peak { float v; int idx; };
@@ -189,6 +288,30 @@ __global__ __launch_bounds__(256) void line_decode_kernel(const float* __restric
 }
 
 }  // namespace
+
+namespace sncal {
+
+size_t logsoftmax_decode_scratch(int B, int C, int h, int w) {
+    const int nstrips = (h + RC_ROWS - 1) / RC_ROWS;
+    return ((size_t)B * (C - 1) * h + (size_t)B * nstrips * (C - 1) * w) * sizeof(float);
+}
+
+int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int h, int w, int img_h, int img_w, float* scratch,
+                             float* kpts, hipStream_t s) {
+    if (C > 64 || C < 2 || cstride % 4 != 0) { set_error("fused log-softmax decode supports 2..64 classes"); return SNCAL_ERR_ARG; }
+    if (w > 8192 || h > 8192) { set_error("fused log-softmax decode: heatmap %dx%d too large", h, w); return SNCAL_ERR_ARG; }
+    const int nstrips = (h + RC_ROWS - 1) / RC_ROWS;
+    float* rowmax = scratch;
+    float* colpart = scratch + (size_t)B * (C - 1) * h;
+    hipLaunchKernelGGL(logsoftmax_rowcol_kernel, dim3(nstrips, B), dim3(256), 0, s, logits, cstride, C, h, w, rowmax, colpart, nstrips);
+    SNCAL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowmax, colpart, nstrips,
+                       C - 1, h, w, img_h, img_w, kpts);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+}  // namespace sncal
 
 extern "C" int sncal_heatmap_decode(const float* d_logp, int B, int C, int h, int w, int img_h, int img_w,
                                     float* d_out, void* stream) {

@@ -880,7 +880,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
         hipEvent_t prev = nullptr;
         if (net->profiling) { prev = next_event(*net); if (prev) SNCAL_CHECK_HIP(hipEventRecord(prev, stream)); }
-        bool skip_next = false;
+        bool skip_next = false, decoded = false;
         for (size_t oi = 0; oi < net->ops.size(); ++oi) {
             const Op& op = net->ops[oi];
             if (!op_active(*net, op)) continue;
@@ -946,6 +946,17 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                 }
                 case OP_SOFTMAX: {
                     const Tensor& tl = net->tensors[op.in];
+                    // nobody wants the heatmap (predict() / the pipeline): log-softmax and the keypoint decode run fused and the
+                    // (B,C,h,w) tensor is never written; its workspace slot serves as the (much smaller) scratch
+                    static const bool fuse_decode = !(getenv("SNCAL_FUSE_DECODE") && atoi(getenv("SNCAL_FUSE_DECODE")) == 0);
+                    if (fuse_decode && !d_heat && d_kpts && !net->desc.head_softmax &&
+                        logsoftmax_decode_scratch(sb, C, tl.H, tl.W) <= (size_t)sb * C * th.H * th.W * sizeof(float)) {
+                        rc = launch_logsoftmax_decode(reinterpret_cast<const float*>(ws + tl.offset), tl.C, C, sb, tl.H, tl.W, img_h, img_w,
+                                                      heat, d_kpts + (size_t)b0 * (C - 1) * 3, stream);
+                        decoded = true;
+                        if (net->profiling) { net->last_kernel = "logsoftmax_decode_fused"; net->last_bytes = (double)sb * tl.H * tl.W * tl.C * 4; }
+                        break;
+                    }
                     rc = launch_softmax_nchw(reinterpret_cast<const float*>(ws + tl.offset), tl.C, C, (size_t)sb * tl.H * tl.W,
                                              (size_t)tl.H * tl.W, net->desc.head_softmax ? 0 : 1, heat, stream);
                     break;
@@ -985,7 +996,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     break;
                 }
                 case OP_DECODE:
-                    if (d_kpts) rc = sncal_heatmap_decode(heat, sb, C, th.H, th.W, img_h, img_w, d_kpts + (size_t)b0 * (C - 1) * 3, stream_);
+                    if (d_kpts && !decoded) rc = sncal_heatmap_decode(heat, sb, C, th.H, th.W, img_h, img_w, d_kpts + (size_t)b0 * (C - 1) * 3, stream_);
                     break;
             }
             if (rc) return rc;
@@ -1005,7 +1016,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         net->last_bytes = (double)sb * H * W * (3 * 4 + net->ge * net->esize);
                     }
                 }
-                if (op.type == OP_DECODE && !d_kpts) continue;
+                if (op.type == OP_DECODE && (!d_kpts || decoded)) continue;
                 hipEvent_t e1 = next_event(*net);
                 if (e1) {
                     SNCAL_CHECK_HIP(hipEventRecord(e1, stream));

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include "ops.hpp"
+#include "softmax_px.hpp"
 
 namespace sncal {
 
@@ -156,30 +157,12 @@ __global__ __launch_bounds__(256) void softmax_nchw_kernel(const float* __restri
     const int t = threadIdx.x, px = t >> 2, q = t & 3;
     for (size_t p0 = (size_t)blockIdx.x * 64; p0 < npix_total; p0 += (size_t)gridDim.x * 64) {
         const size_t p = p0 + px;
-        float v[16];
-        const bool live = p < npix_total;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            const int c = q * 16 + j * 4;
-            if (live && c < cstride) f = *reinterpret_cast<const float4*>(logits + p * cstride + c);
-            v[j * 4 + 0] = c + 0 < C ? f.x : -INFINITY; v[j * 4 + 1] = c + 1 < C ? f.y : -INFINITY;
-            v[j * 4 + 2] = c + 2 < C ? f.z : -INFINITY; v[j * 4 + 3] = c + 3 < C ? f.w : -INFINITY;
-        }
-        float m = v[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64));
-        float e[16], ssum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { e[j] = (q * 16 + j < C) ? expf(v[j] - m) : 0.f; ssum += e[j]; }
-        ssum += __shfl_xor(ssum, 1, 64);
-        ssum += __shfl_xor(ssum, 2, 64);
-        const float ls = logf(ssum), inv = 1.0f / ssum;
+        float v[16], rv[16];
+        load_px16(logits, p, cstride, C, q, p < npix_total, v);
+        softmax_px16(v, q, C, log_mode, rv);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s_t[q * 16 + j][px] = log_mode ? (v[j] - m) - ls : e[j] * inv;
+        for (int j = 0; j < 16; ++j) s_t[q * 16 + j][px] = rv[j];
         __syncthreads();
         const int lp = t & 63;
         const size_t pp = p0 + lp;

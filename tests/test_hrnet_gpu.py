@@ -145,3 +145,24 @@ def test_fused_basicblock_is_bit_identical_to_two_convs(sncal, cuda, monkeypatch
         assert ('bblock48_fused' in kernels) == (flag == '1')
         outs.append(heat.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('cfg_name,hw', [('hrnet_w18', (64, 96)), ('hrnet_w18', (135, 240)), ('hrnet_w48', (540, 960))])
+def test_fused_logsoftmax_decode_is_bit_identical(sncal, cuda, cfg_name, hw):
+    """predict() without the heatmap runs log-softmax + keypoint decode fused (decode.hip: the (B,58,h,w) tensor is
+    never written).  Same per-pixel arithmetic (softmax_px.hpp) and exact maxima, so the keypoints must equal, bit for
+    bit, those decoded from the heatmap the unfused path writes -- including sizes that are not multiples of the
+    64-pixel tile or the 18-row strip."""
+    cfg = hr.load_config(cfg_name)
+    net = sncal.HRNetHeatmap(cfg_name, dtype='bf16', device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 7, 3.0))
+    x = hr.seeded_input(3, hw[0], hw[1], 11).to(cuda)
+    net.set_profiling(True)
+    _, k_fused = net.forward(x, want_heat=False, decode_size=(540, 960))
+    kernels = {p['kernel'] for p in net.get_profile()}
+    assert 'logsoftmax_decode_fused' in kernels and 'softmax_nchw' not in kernels
+    net.set_profiling(False)
+    heat, k_heat = net.forward(x, want_heat=True, decode_size=(540, 960))
+    assert torch.equal(k_fused, k_heat)
+    ref = od.keypoint_decode(heat.cpu().numpy(), (540, 960))
+    assert np.array_equal(k_fused.cpu().numpy()[..., :2], ref[..., :2])

@@ -266,6 +266,15 @@ void sncal_jpeg_destroy(sncal_jpeg* dec);
 int sncal_jpeg_decode(sncal_jpeg* dec, const unsigned char* const* data, const size_t* len, int B,
                       unsigned char* d_bgr, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N4 (heatmap half)  training-target synthesis
+ * replaces HRNetLoss.create_target = create_heatmaps + background channel     src/models/hrnet/loss.py:7-52, 81-87
+ *   d_kpts (B,N,3) fp32 [x, y, visibility] in heatmap pixels (already divided by the loss stride, loss.py:92)
+ *   d_out  (B,N+1,h,w) fp32: N separable amplitude-1 Gaussians (zero where the point is not "visible" by the
+ *          reference's own test any(keypoints == 1, dim=-1), loss.py:49) and 1 - max over them as channel N.
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_create_target(const float* d_kpts, int B, int N, float sigma, int h, int w, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,25 @@ def synth_keypoints(seed: int, sigma_px: float = 1.0, grid: float = 2.0, outlier
     return kp, cam
 
 
+def create_target(kp: np.ndarray, sigma: float, hw) -> np.ndarray:
+    """HRNetLoss.create_target, loss.py:81-87 with the reference's visibility test (loss.py:49: any component == 1);
+    kp (B,N,3) [x, y, vis] in heatmap pixels.  exp is float32(exp(float64)), the correctly rounded value."""
+    kp = np.asarray(kp, dtype=np.float32)
+    h, w = hw
+    sig = np.float32(sigma)
+
+    def g(r, mu):
+        d = ((r - mu[..., None]) / sig).astype(np.float32)
+        return np.exp((-(d * d).astype(np.float32) / np.float32(2.0)).astype(np.float64)).astype(np.float32)
+    gx = g(np.arange(w, dtype=np.float32), kp[..., 0])
+    gy = g(np.arange(h, dtype=np.float32), kp[..., 1])
+    hm = (gx[:, :, None, :] * gy[:, :, :, None]).astype(np.float32)
+    vis = np.any(kp == np.float32(1.0), axis=-1)
+    hm = np.where(vis[..., None, None], hm, np.float32(0)).astype(np.float32)
+    bg = (np.float32(1.0) - hm.max(axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([hm, bg], axis=1)
+
+
 def gaussian_heatmaps(kp_hm: np.ndarray, visible: np.ndarray, sigma: float, hw) -> np.ndarray:
     """loss.py:7-52 + :81-87: (B,N,2) keypoints in heatmap units -> (B,N+1,h,w) fp32 heatmaps
     (amplitude-1 separable Gaussians; last channel = 1 - max over keypoint channels)."""

@@ -93,6 +93,7 @@ SIGNATURES = {
     'sncal_jpeg_destroy': (None, [vp]),
     'sncal_jpeg_decode': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
                                          ctypes.c_int, vp, vp]),
+    'sncal_create_target': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, vp, vp]),
     'sncal_calibrate': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp]),
 }
 

@@ -163,3 +163,33 @@ def test_jpeg_oracle_matches_libjpeg_turbo_capture(gold_dir):
     assert np.array_equal(full[256:304, 448:512], g['bgr.full.tile'])
     with pytest.raises(oj.JpegError):
         oj.decode_bgr(g['jpg.progressive'].tobytes())
+
+
+def _target_close(ref, got, n_kp):
+    """Tolerance of the N4 target: keypoint channels within 4 ulp of the reference's torch values wherever those are
+    normal numbers (torch's vectorised exp vs the correctly rounded exp, times two factors), background channel
+    (1 - max) within 2 ulp of 1.0."""
+    ulp = np.abs(ref.view(np.int32).astype(np.int64) - got.view(np.int32).astype(np.int64))
+    normal = np.abs(ref) > 1e-30
+    normal[:, n_kp] = False
+    return ulp[normal].max() <= 4 and np.abs(ref - got)[~normal].max() <= 2.4e-7
+
+
+def test_target_oracle_matches_reference_capture(gold_dir):
+    """N4: HRNetLoss.create_target captured from the imported reference (tools/make_golden.py gen_target), including the
+    `any(keypoints == 1)` visibility quirk of loss.py:49."""
+    g = np.load(os.path.join(gold_dir, 'target.npz'))
+    kp, sigma, hw = g['small.kp'], float(g['small.sigma']), tuple(g['small.hw'])
+    got = synth.create_target(kp, sigma, hw)
+    assert got.shape == g['small.target'].shape and _target_close(g['small.target'], got, kp.shape[1])
+    assert got[0, 0].max() > 0.5 and got[0, 1].max() > 0.5 and not got[0, 2].any()      # x == 1 / y == 1 visible, flag 0 not
+    kp, sigma, hw = g['train.kp'], float(g['train.sigma']), tuple(g['train.hw'])
+    got = synth.create_target(kp, sigma, hw)
+    n = kp.shape[1]
+    planes = got[:, [0, 1, 2, 3, 30, n]]
+    ref = g['train.planes']
+    ulp = np.abs(ref.view(np.int32).astype(np.int64) - planes.view(np.int32).astype(np.int64))
+    normal = np.abs(ref) > 1e-30
+    normal[:, -1] = False
+    assert ulp[normal].max() <= 4 and np.abs(ref - planes)[~normal].max() <= 2.4e-7
+    assert np.allclose(got.astype(np.float64).sum(axis=(2, 3)), g['train.chan_sum'], rtol=1e-6, atol=1e-4)

@@ -436,6 +436,45 @@ def gen_jpeg():
           len(data), 'bytes')
 
 
+def gen_target():
+    """N4: HRNetLoss.create_target of the imported reference (loss.py:81-87) on keypoints that cover its visibility quirk
+    (any component == 1), points outside the canvas, sub-pixel centres, and the training configuration
+    (sigma 3, stride 2, pred_size 270x480; train_config.yaml:38-40) -- stored sparsely (a few planes + checksums)."""
+    import torch
+    from src.models.hrnet.loss import HRNetLoss
+    from oracle import synth
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = {'small': (3, 7, 2.0, (20, 33)), 'train': (2, 57, 3.0, (270, 480))}
+    for name, (B, N, sigma, hw) in cases.items():
+        kp = np.zeros((B, N, 3), np.float32)
+        kp[..., 0] = rng.uniform(-5, hw[1] + 5, (B, N))
+        kp[..., 1] = rng.uniform(-5, hw[0] + 5, (B, N))
+        kp[..., 2] = (rng.uniform(size=(B, N)) < 0.7).astype(np.float32)
+        kp[0, 0] = (1.0, 7.25, 0.0)          # x == 1 makes it "visible" although the flag is 0 (loss.py:49)
+        kp[0, 1] = (5.5, 1.0, 0.0)           # y == 1 likewise
+        kp[0, 2] = (4.0, 6.0, 0.0)           # really invisible
+        kp[0, 3] = (10.0, 3.0, 1.0)
+        loss = HRNetLoss(num_refinement_stages=0, sigma=sigma, stride=1, pred_size=hw, num_keypoints=N)
+        ref = loss.create_target(torch.from_numpy(kp)).numpy()
+        mine = synth.create_target(kp, sigma, hw)
+        ulp = np.abs(ref.view(np.int32).astype(np.int64) - mine.view(np.int32).astype(np.int64))
+        normal = np.abs(ref) > 1e-30          # torch's vectorised exp flushes / rounds differently in the denormal range
+        normal[:, N] = False                  # background = 1 - max: an ulp of the maximum is many ulps of the difference
+        assert ulp[normal].max() <= 4 and np.abs(ref - mine)[~normal].max() <= 2.4e-7, (ulp[normal].max(), np.abs(ref - mine)[~normal].max())
+        ulp = ulp[normal]
+        out[f'{name}.kp'] = kp
+        out[f'{name}.sigma'] = np.float32(sigma)
+        out[f'{name}.hw'] = np.array(hw)
+        if name == 'small':
+            out[f'{name}.target'] = ref
+        else:
+            out[f'{name}.planes'] = ref[:, [0, 1, 2, 3, 30, N]]
+            out[f'{name}.chan_sum'] = ref.astype(np.float64).sum(axis=(2, 3))
+        print('target', name, 'ok: max ulp distance oracle vs reference', int(ulp.max()))
+    np.savez_compressed(os.path.join(GOLD, 'target.npz'), **out)
+
+
 def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, batch=1):
     from oracle import hrnet_ref as hr, decode as od
     cfg = hr.load_config(cfg_name)
@@ -494,7 +533,7 @@ def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'jpeg', 'hrnet']
+    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'jpeg', 'target', 'hrnet']
     if 'pitch' in which:
         gen_pitch()
     if 'decode' in which:
@@ -509,6 +548,8 @@ if __name__ == '__main__':
         gen_evaluator()
     if 'jpeg' in which:
         gen_jpeg()
+    if 'target' in which:
+        gen_target()
     if 'hrnet' in which:
         gen_hrnet('hrnet_w18_64x96', 'hrnet_w18', (64, 96), 3, 4.0)
         gen_hrnet('hrnet_w18_135x240', 'hrnet_w18', (135, 240), 5, 4.0, store_full=False, batch=2)

@@ -203,10 +203,19 @@ int launch_upsample_add(int dtype, const UpsampleAddParams& p0, hipStream_t s) {
     const int ge = dtype == SNCAL_BF16 ? 8 : 4;
     const unsigned cg = (unsigned)(p.C / ge);
     const size_t per_img = (size_t)p.H * p.W * cg;
-    // multiply-high division is exact while dividend * divisor < 2^32: (element index, cg) and (pixel index, W)
-    if (per_img >= (1ull << 31) || per_img * cg >= (1ull << 32) || (size_t)p.H * p.W * p.W >= (1ull << 32)) { set_error("upsample_add: image of %d x %d x %d is too large", p.H, p.W, p.C); return SNCAL_ERR_ARG; }
+    // multiply-high division by m = floor((2^32 - 1) / d) + 1 is exact for every x with x * (m * d - 2^32) < 2^32
+    // (the error term m * d - 2^32 is < d, and 0 for powers of two): checked for (element index, cg) and (pixel index, W)
     p.cg_magic = cg <= 1 ? 0u : 0xFFFFFFFFu / cg + 1u;
     p.w_magic = p.W <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)p.W + 1u;
+    auto exact = [](unsigned long long xmax, unsigned d, unsigned magic) {
+        if (d <= 1) return true;
+        const unsigned long long err = (unsigned long long)magic * d - (1ull << 32);
+        return xmax * err < (1ull << 32);
+    };
+    if (per_img >= (1ull << 31) || !exact(per_img, cg, p.cg_magic) || !exact((unsigned long long)p.H * p.W, (unsigned)p.W, p.w_magic)) {
+        set_error("upsample_add: image of %d x %d x %d is too large", p.H, p.W, p.C);
+        return SNCAL_ERR_ARG;
+    }
     const dim3 grid((unsigned)std::min<size_t>((per_img + 255) / 256, 2048), (unsigned)p.N);
     if (dtype == SNCAL_BF16)
         hipLaunchKernelGGL(upsample_add_kernel<__bf16>, grid, dim3(256), 0, s, p);

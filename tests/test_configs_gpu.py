@@ -94,6 +94,32 @@ def test_c5_1080p_shapes(sncal, cuda):
     assert np.array_equal(kp.cpu().numpy()[..., :2], od.keypoint_decode(ref, (540, 960))[..., :2])
 
 
+def test_c5_w48_1080p_flagship(sncal, cuda):
+    """C5 shapes on the flagship network: HRNet-W48 at 1920x1080.  fp32 engine vs the oracle on one frame (identical
+    keypoint indices, |dlogp| <= 2e-4); bf16 engine (the fused BasicBlock / head / decode kernels at 270x480 branch
+    maps and a 540x960 head) on a small batch: same keypoint cells as the fp32 engine up to the bf16 drift bound used
+    for C3.  fp8 arithmetic is not built."""
+    cfg = hr.load_config('hrnet_w48')
+    sd = hr.seeded_state_dict(cfg, 1, 1.5)
+    x = hr.seeded_input(2, 1080, 1920, 41)
+    net32 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp32', device=cuda)
+    net32.load_state_dict(sd)
+    heat, kp32 = net32.forward(x[:1].to(cuda), want_heat=True, decode_size=(1080, 1920))
+    assert heat.shape == (1, 58, 540, 960)
+    ref = hr.forward(sd, x[:1], cfg).numpy()
+    assert np.abs(heat.cpu().numpy() - ref).max() <= 2e-4
+    assert np.array_equal(kp32.cpu().numpy()[..., :2], od.keypoint_decode(ref, (1080, 1920))[..., :2])
+    del heat, net32
+    torch.cuda.empty_cache()
+    net16 = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    net16.load_state_dict(sd)
+    h16, k16 = net16.forward(x.to(cuda), want_heat=True, decode_size=(1080, 1920))
+    _, k16b = net16.forward(x.to(cuda), want_heat=False, decode_size=(1080, 1920))
+    assert torch.equal(k16, k16b)                                  # fused decode at 540x960
+    d = np.abs(h16[:1].cpu().numpy() - ref)
+    assert d.mean() < 0.12 and d.max() < 1.0, (d.mean(), d.max())
+
+
 def test_pipeline_overlapped_solve_matches_direct(sncal, cuda):
     """CalibrationPipeline (side-stream solve) returns the same cameras as the synchronous calls."""
     cfg = hr.load_config('hrnet_w18')

@@ -20,6 +20,7 @@
 // All arithmetic is fp64.  The solve is latency-bound (~1e5 FLOP per frame): it is reported in frames/s,
 // not as a roofline fraction, and runs on its own stream beside the MFMA-bound network.
 #include "common.hpp"
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -939,18 +940,9 @@ __device__ int original_voter(const float* kp, const float* line_pts, const snca
 }
 
 // prediction.py:259-330
-__device__ int voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
-    u64 mask = select_points(kp[2], thr, false, 0);
-    mask = add_line_points(mask, p, line_pts, cfg, 1, 0);
-    Cam hom;
-    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+// the final choice among the homography camera and the four subset cameras (prediction.py:293-329)
+__device__ int voter_select(const sncal_voter_cfg& cfg, int hs, const Cam& hom, const int (&st)[4], const Cam (&cands)[4], Cam& out) {
     if (hs == ST_RAISE) return ST_RAISE;
-    Cam cands[4];
-    int st[4];
-    st[2] = camera_all_points(mask, p, cfg.img_w, cfg.img_h, cands[2]);
-    st[0] = camera_all_points(mask & KEEP_MASK, p, cfg.img_w, cfg.img_h, cands[0]);
-    st[1] = camera_accurate_points(mask, p, 5.0, cfg.img_w, cfg.img_h, cands[1]);
-    st[3] = camera_all_points(mask & GROUND_MASK, p, cfg.img_w, cfg.img_h, cands[3]);
     const int tags[4] = {SNCAL_CAM_VOTER_REL, SNCAL_CAM_VOTER_ACC, SNCAL_CAM_VOTER_ALL, SNCAL_CAM_VOTER_GROUND};
     int best = -1;
     bool best_flag = false;
@@ -965,6 +957,55 @@ __device__ int voter(const float* kp, const float* line_pts, const sncal_voter_c
     if (best >= 0 && cands[best].rmse < cfg.max_rmse) { out = cands[best]; out.tag = tags[best]; return ST_OK; }
     if (hs == ST_OK && hom.rmse < cfg.max_rmse) { out = hom; out.tag = SNCAL_CAM_VOTER_HOM; return ST_OK; }
     return ST_NONE;
+}
+
+__device__ int voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
+    u64 mask = select_points(kp[2], thr, false, 0);
+    mask = add_line_points(mask, p, line_pts, cfg, 1, 0);
+    Cam hom;
+    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+    if (hs == ST_RAISE) return ST_RAISE;
+    Cam cands[4];
+    int st[4];
+    st[2] = camera_all_points(mask, p, cfg.img_w, cfg.img_h, cands[2]);
+    st[0] = camera_all_points(mask & KEEP_MASK, p, cfg.img_w, cfg.img_h, cands[0]);
+    st[1] = camera_accurate_points(mask, p, 5.0, cfg.img_w, cfg.img_h, cands[1]);
+    st[3] = camera_all_points(mask & GROUND_MASK, p, cfg.img_w, cfg.img_h, cands[3]);
+    return voter_select(cfg, hs, hom, st, cands, out);
+}
+
+// The same voter spread over the four waves of a workgroup: its five cameras are independent solves of the same
+// points (prediction.py:281-291 builds them one after the other), so wave 0 takes the homography camera and the
+// ground-plane subset, waves 1..3 the all / reliable / H-consistent subsets; every wave then runs the (cheap) selection
+// on the five results in LDS.  Each camera is computed by the same code on the same inputs as in voter(): identical bits.
+struct VoterShared { Cam hom; Cam cands[4]; int hs; int st[4]; };
+
+__device__ int voter_parallel(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, VoterShared& sh,
+                              Cam& out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u64 mask = select_points(kp[2], thr, false, 0);
+    mask = add_line_points(mask, p, line_pts, cfg, 1, 0);
+    Cam c;
+    c.tag = SNCAL_CAM_NONE;
+    if (wave == 0) {
+        const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.hom = c; sh.hs = hs; }
+        const int s3 = camera_all_points(mask & GROUND_MASK, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.cands[3] = c; sh.st[3] = s3; }
+    } else if (wave == 1) {
+        const int s2 = camera_all_points(mask, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.cands[2] = c; sh.st[2] = s2; }
+    } else if (wave == 2) {
+        const int s0 = camera_all_points(mask & KEEP_MASK, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.cands[0] = c; sh.st[0] = s0; }
+    } else {
+        const int s1 = camera_accurate_points(mask, p, 5.0, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.cands[1] = c; sh.st[1] = s1; }
+    }
+    __syncthreads();
+    const int r = voter_select(cfg, sh.hs, sh.hom, sh.st, sh.cands, out);
+    __syncthreads();                                   // everyone has read the results before the next pass overwrites them
+    return r;
 }
 
 // prediction.py:138-170
@@ -1010,8 +1051,48 @@ __device__ void load_points(const float* kp, Pts& p) {
 // One wavefront per frame, four frames per workgroup: a solver wave owns a whole SIMD register file (512 VGPRs), so a
 // lone wave per CU would keep the co-running convolution workgroups (one wave on each SIMD) off that CU; packed, 64
 // frames block 16 CUs instead of degrading 64.  The waves of a workgroup never communicate.
+constexpr int STATUS_PENDING = -1;      // iterative_voter frames whose original_voter pass found no camera: left for voter_kernel
+
+__device__ __forceinline__ void store_camera(sncal_camera* out, int st, const Cam& cam) {
+    sncal_camera o;
+    memset(&o, 0, sizeof(o));
+    if (st == ST_OK) {
+        for (int i = 0; i < 3; ++i) o.position[i] = cam.pos[i];
+        for (int i = 0; i < 9; ++i) o.rotation[i] = cam.R[i];
+        o.fx = cam.fx; o.fy = cam.fy; o.cx = cam.cx; o.cy = cam.cy; o.rmse = cam.rmse;
+        o.status = cam.tag;
+    }
+    *out = o;
+}
+
+// iterative_voter's second half (prediction.py:250-256) for the frames calibrate_kernel left pending: one workgroup per
+// frame, the voter's five cameras on four waves.  Frames that already have a camera leave at once.
+__global__ __launch_bounds__(256, 1) void voter_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts, int B,
+                                                       sncal_voter_cfg cfg, sncal_camera* __restrict__ out) {
+    __shared__ VoterShared sh;
+    const int frame = blockIdx.x;
+    if (out[frame].status != STATUS_PENDING) return;
+    const int lane = threadIdx.x & 63;
+    float kp[3] = {0.f, 0.f, -1.f};
+    if (lane < NPTS) {
+        const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
+        kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
+    }
+    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    Pts p;
+    load_points(kp, p);
+    Cam cam;
+    cam.tag = SNCAL_CAM_NONE;
+    int st = ST_NONE;
+    for (int i = 0; i < cfg.n_conf_threshs; ++i) {
+        st = voter_parallel(kp, lp, cfg, cfg.conf_threshs[i], p, sh, cam);
+        if (st != ST_NONE) break;                      // camera found, or an exception leaves iterative_voter
+    }
+    if (threadIdx.x == 0) store_camera(out + frame, st, cam);
+}
+
 __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
-                                                           int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out) {
+                                                           int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out, int defer_voter) {
     const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (frame >= B) return;
     const int lane = threadIdx.x & 63;
@@ -1029,6 +1110,10 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     switch (cfg.algorithm) {
         case 0: {   // iterative_voter, prediction.py:245-257
             st = original_voter(kp, lp, cfg, 0.5, p, cam);
+            if (st != ST_OK && defer_voter) {
+                if (lane == 0) { store_camera(out + frame, ST_NONE, cam); out[frame].status = STATUS_PENDING; }
+                return;
+            }
             if (st != ST_OK) {
                 st = ST_NONE;
                 for (int i = 0; i < cfg.n_conf_threshs; ++i) {
@@ -1043,17 +1128,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
         case 3: st = opencv_calibration(kp, cfg, p, cam); break;
         default: st = opencv_calibration_multiplane(kp, lp, cfg, p, cam); break;
     }
-    if (lane == 0) {
-        sncal_camera o;
-        memset(&o, 0, sizeof(o));
-        if (st == ST_OK) {
-            for (int i = 0; i < 3; ++i) o.position[i] = cam.pos[i];
-            for (int i = 0; i < 9; ++i) o.rotation[i] = cam.R[i];
-            o.fx = cam.fx; o.fy = cam.fy; o.cx = cam.cx; o.cy = cam.cy; o.rmse = cam.rmse;
-            o.status = cam.tag;
-        }
-        out[frame] = o;
-    }
+    if (lane == 0) store_camera(out + frame, st, cam);
 }
 
 // stand-alone Camera.refine_camera / Camera.solve_pnp on caller-provided 3-D / 2-D matches
@@ -1169,8 +1244,17 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     SNCAL_CHECK_ARG(cfg->img_w > 1 && cfg->img_h > 1, "sncal_calibrate: image size");
     const int rc = ensure_pitch_uploaded();
     if (rc) return rc;
-    hipLaunchKernelGGL(calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+    // iterative_voter: frames whose first pass (original_voter) fails fall through to the voter at up to three thresholds,
+    // 4x the work of the common case; in one kernel they were stragglers that set its duration (8.5 ms for 64 frames of
+    // which 61 were done after 2.7 ms).  They are finished by a second launch that spreads the voter over four waves.
+    static const bool split = !(getenv("SNCAL_SOLVE_SPLIT") && atoi(getenv("SNCAL_SOLVE_SPLIT")) == 0);      // tuning aid
+    const int defer = (cfg->algorithm == 0 && split && cfg->n_conf_threshs > 0) ? 1 : 0;
+    hipLaunchKernelGGL(calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out, defer);
     SNCAL_CHECK_LAUNCH();
+    if (defer) {
+        hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+        SNCAL_CHECK_LAUNCH();
+    }
     return SNCAL_OK;
 }
 

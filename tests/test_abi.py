@@ -142,3 +142,38 @@ def test_jpeg_host_stage_matches_oracle_and_refuses_what_it_cannot_decode():
     big = np.zeros(sum(sncal_amd.jpeg.probe(good)['blocks']) * 64, np.int16)
     st = L.lib().sncal_jpeg_entropy_decode(broken, len(broken), big.ctypes.data, big.size, ctypes.byref(info))
     assert st == -1 and b'MCU' in L.lib().sncal_last_error()
+
+
+def test_argument_validation_and_empty_batches_without_a_gpu():
+    """Every compute entry point validates its arguments before touching the device and accepts an empty batch:
+    statuses and messages as include/sncal.h documents (no kernel is launched here)."""
+    import sncal_amd
+    L = sncal_amd._lib
+    lib = L.lib()
+    ERR_ARG = -1
+    one = ctypes.c_void_p(16)                     # a non-null dummy pointer; never dereferenced on these paths
+    cfg = L.VoterCfg()
+    cfg.algorithm, cfg.n_conf_threshs, cfg.img_w, cfg.img_h = 0, 3, 960, 540
+    # empty batches
+    assert lib.sncal_heatmap_decode(None, 0, 58, 270, 480, 540, 960, None, None) == 0
+    assert lib.sncal_line_decode(None, 0, 23, 135, 240, 3.0, 4.0, None, None) == 0
+    assert lib.sncal_lines_to_points(None, 0, 4.0, 0.0, None, None) == 0
+    assert lib.sncal_calibrate(None, None, 0, ctypes.byref(cfg), None, None) == 0
+    assert lib.sncal_create_target(None, 0, 57, 3.0, 270, 480, None, None) == 0
+    assert lib.sncal_evaluate_cameras(None, 0, None, None, None, 26, None, None, None, 4, 5.0, 960, 540, None, None) == 0
+    # bad shapes / null pointers
+    assert lib.sncal_heatmap_decode(one, 1, 1, 270, 480, 540, 960, one, None) == ERR_ARG          # C < 2
+    assert lib.sncal_heatmap_decode(None, 1, 58, 270, 480, 540, 960, one, None) == ERR_ARG and b'null' in lib.sncal_last_error()
+    assert lib.sncal_line_decode(one, 1, 23, 135, 240, 0.0, 4.0, one, None) == ERR_ARG             # sigma <= 0
+    assert lib.sncal_calibrate(None, None, 1, ctypes.byref(cfg), one, None) == ERR_ARG
+    cfg.algorithm = 9
+    assert lib.sncal_calibrate(one, None, 1, ctypes.byref(cfg), one, None) == ERR_ARG and b'algorithm' in lib.sncal_last_error()
+    assert lib.sncal_create_target(one, 1, 65, 3.0, 8, 8, one, None) == ERR_ARG
+    assert lib.sncal_create_target(one, 1, 57, -1.0, 8, 8, one, None) == ERR_ARG
+    assert lib.sncal_evaluate_cameras(one, 1, one, one, one, 64, one, one, one, 4, 5.0, 960, 540, one, None) == ERR_ARG   # n_cls > 32
+    assert lib.sncal_jpeg_create(0, 540, 960, 1, ctypes.byref(ctypes.c_void_p())) == ERR_ARG
+    assert lib.sncal_jpeg_decode(None, None, None, 1, None, None) == ERR_ARG
+    desc = L.HRNetDesc()
+    h = ctypes.c_void_p()
+    assert lib.sncal_hrnet_create(ctypes.byref(desc), 1, ctypes.byref(h)) == ERR_ARG               # zeroed descriptor
+    assert lib.sncal_hrnet_forward(None, None, 1, 540, 960, None, None, 540, 960, None, 0, None) == ERR_ARG

@@ -10,6 +10,7 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+LaunchEvents& launch_events() { static thread_local LaunchEvents e; return e; }
 }  // namespace sncal
 
 extern "C" int sncal_version(void) { return SNCAL_VERSION; }

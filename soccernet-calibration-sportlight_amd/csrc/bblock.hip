@@ -224,7 +224,7 @@ int launch_bblock48(const BBlockParams& p0, hipStream_t s) {
     const size_t nwg = (size_t)p.tiles_x * p.tiles_y * p.N;
     p.trace = nullptr;
     if (trace_file && hipMalloc(&p.trace, nwg * 128) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, nwg * 128, s);
-    hipLaunchKernelGGL(bblock48_kernel, dim3((unsigned)nwg), dim3(256), (size_t)BB_LDS, s, p);
+    SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)nwg), dim3(256), (size_t)BB_LDS, s, p);
     SNCAL_CHECK_LAUNCH();
     if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run
         std::vector<unsigned long long> h(nwg * 16);

@@ -43,6 +43,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "common.hpp"
 
 namespace sncal {
 
@@ -499,7 +500,7 @@ void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
+    SNCAL_LAUNCH((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

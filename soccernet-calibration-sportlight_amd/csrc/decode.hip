@@ -303,9 +303,9 @@ int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int
     const int nstrips = (h + RC_ROWS - 1) / RC_ROWS;
     float* rowmax = scratch;
     float* colpart = scratch + (size_t)B * (C - 1) * h;
-    hipLaunchKernelGGL(logsoftmax_rowcol_kernel, dim3(nstrips, B), dim3(256), 0, s, logits, cstride, C, h, w, rowmax, colpart, nstrips);
+    SNCAL_LAUNCH_FIRST(logsoftmax_rowcol_kernel, dim3(nstrips, B), dim3(256), 0, s, logits, cstride, C, h, w, rowmax, colpart, nstrips);
     SNCAL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowmax, colpart, nstrips,
+    SNCAL_LAUNCH_LAST(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowmax, colpart, nstrips,
                        C - 1, h, w, img_h, img_w, kpts);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
@@ -325,7 +325,7 @@ extern "C" int sncal_heatmap_decode(const float* d_logp, int B, int C, int h, in
     const int nq = (nvec + 63) / 64;
     dim3 grid(B * C), block(256);
     hipStream_t s = sncal::as_stream(stream);
-#define LAUNCH(V, Q) hipLaunchKernelGGL((kp_decode_kernel<V, Q>), grid, block, lds, s, d_logp, C, h, w, img_h, img_w, d_out)
+#define LAUNCH(V, Q) SNCAL_LAUNCH((kp_decode_kernel<V, Q>), grid, block, lds, s, d_logp, C, h, w, img_h, img_w, d_out)
     if (vec4) {
         if (nq <= 1) LAUNCH(4, 1); else if (nq <= 2) LAUNCH(4, 2); else if (nq <= 4) LAUNCH(4, 4); else LAUNCH(4, 8);
     } else {

@@ -276,8 +276,8 @@ void launch_one(const HeadParams& q, unsigned blocks, hipStream_t s) {
     // resident waves (25 KB of LDS, 92 VGPRs -> 5 per SIMD), not prefetch depth (measured 5.8 vs 6.9 ms)
     static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 0;     // tuning aid
     const size_t lds1 = (size_t)(NSRC * HEAD_SRC_LDS + (2 * KS1 + M2 + 1) * 1024);
-    if (db) hipLaunchKernelGGL((head_fused_kernel<M2, NSRC, KS1, NP, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-    else hipLaunchKernelGGL((head_fused_kernel<M2, NSRC, KS1, NP, 0>), dim3(blocks), dim3(256), lds1, s, q);
+    if (db) SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+    else SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 0>), dim3(blocks), dim3(256), lds1, s, q);
 }
 
 template <int M2, int NP>

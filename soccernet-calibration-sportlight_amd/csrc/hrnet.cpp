@@ -878,14 +878,14 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
     for (int b0 = 0; b0 < B; b0 += SB) {
         const int sb = std::min(SB, B - b0);
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
-        hipEvent_t prev = nullptr;
-        if (net->profiling) { prev = next_event(*net); if (prev) SNCAL_CHECK_HIP(hipEventRecord(prev, stream)); }
         bool skip_next = false, decoded = false;
         for (size_t oi = 0; oi < net->ops.size(); ++oi) {
             const Op& op = net->ops[oi];
             if (!op_active(*net, op)) continue;
             if (skip_next) { skip_next = false; continue; }      // second conv of a fused BasicBlock
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (net->profiling) { ev0 = next_event(*net); ev1 = next_event(*net); sncal::launch_events() = sncal::LaunchEvents{ev0, ev1}; }
             switch (op.type) {
                 case OP_INPUT:
                     if (d_x8) rc = launch_u8hwc_to_nhwc(net->dtype, d_x8 + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, H, W, stream);
@@ -1000,7 +1000,11 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     break;
             }
             if (rc) return rc;
-            if (net->profiling && prev) {
+            if (net->profiling) {
+                sncal::LaunchEvents& le = sncal::launch_events();
+                const bool launched = !le.start && !le.stop;          // the op's launch consumed the pair
+                le = sncal::LaunchEvents{};
+                if (!launched || !ev0 || !ev1) continue;
                 if (net->last_kernel.empty()) {
                     const char* names[] = {"nchw_to_nhwc", "conv", "upsample_add", "softmax_nchw", "kp_decode", "head_fused"};
                     net->last_kernel = names[op.type];
@@ -1017,12 +1021,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     }
                 }
                 if (op.type == OP_DECODE && (!d_kpts || decoded)) continue;
-                hipEvent_t e1 = next_event(*net);
-                if (e1) {
-                    SNCAL_CHECK_HIP(hipEventRecord(e1, stream));
-                    net->intervals.push_back({prev, e1, net->last_kernel, net->last_flops, net->last_bytes});
-                    prev = e1;
-                }
+                net->intervals.push_back({ev0, ev1, net->last_kernel, net->last_flops, net->last_bytes});
             }
         }
     }

@@ -181,9 +181,9 @@ static inline int grid_for(size_t items) {
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s) {
     const size_t total = (size_t)N * H * W;
     if (dtype == SNCAL_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
+        SNCAL_LAUNCH(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (float*)y, N, C, H, W);
+        SNCAL_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (float*)y, N, C, H, W);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }
@@ -191,9 +191,9 @@ int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H,
 int launch_u8hwc_to_nhwc(int dtype, const unsigned char* x, void* y, int N, int H, int W, hipStream_t s) {
     const size_t total = (size_t)N * H * W;
     if (dtype == SNCAL_BF16)
-        hipLaunchKernelGGL(u8hwc_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)y, total);
+        SNCAL_LAUNCH(u8hwc_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)y, total);
     else
-        hipLaunchKernelGGL(u8hwc_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, total);
+        SNCAL_LAUNCH(u8hwc_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, total);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }
@@ -218,9 +218,9 @@ int launch_upsample_add(int dtype, const UpsampleAddParams& p0, hipStream_t s) {
     }
     const dim3 grid((unsigned)std::min<size_t>((per_img + 255) / 256, 2048), (unsigned)p.N);
     if (dtype == SNCAL_BF16)
-        hipLaunchKernelGGL(upsample_add_kernel<__bf16>, grid, dim3(256), 0, s, p);
+        SNCAL_LAUNCH(upsample_add_kernel<__bf16>, grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(upsample_add_kernel<float>, grid, dim3(256), 0, s, p);
+        SNCAL_LAUNCH(upsample_add_kernel<float>, grid, dim3(256), 0, s, p);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }
@@ -229,7 +229,7 @@ int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_tot
                         float* out, hipStream_t s) {
     if (C > 64 || cstride % 4 != 0) { set_error("softmax head supports at most 64 classes"); return SNCAL_ERR_ARG; }
     const size_t groups = (npix_total + 63) / 64;
-    hipLaunchKernelGGL(softmax_nchw_kernel, dim3((unsigned)(groups > 16384 ? 16384 : groups)), dim3(256), 0, s, logits,
+    SNCAL_LAUNCH(softmax_nchw_kernel, dim3((unsigned)(groups > 16384 ? 16384 : groups)), dim3(256), 0, s, logits,
                        cstride, C, npix_total, hw, log_mode, out);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;

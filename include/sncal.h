@@ -147,6 +147,9 @@ typedef struct {
     double ms;              /* summed event-to-event time                                                */
     int launches;
 } sncal_kernel_stat;
+/* enable: 0 off; 1 time every launch; 2 time only the launches of the kernel variant that led the profile recorded so
+ * far (needs a preceding mode-1 profile; the timing events cost ~4 us per launch, so a timed region that only needs
+ * its dominant kernel's duration should not pay for the other ~150 launches). Every call clears the recorded profile. */
 int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable);
 int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out, int cap, int* count);
 

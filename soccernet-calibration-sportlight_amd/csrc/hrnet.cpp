@@ -106,7 +106,9 @@ struct sncal_hrnet {
     int lay_sb = -1, lay_h = -1, lay_w = -1;
     size_t lay_bytes = 0;
     // profiling (sncal_hrnet_set_profiling): events recorded between launches + what each interval ran
-    bool profiling = false;
+    int profiling = 0;                    // 0 off, 1 every launch, 2 only the launches of `focus` (labels cached per op by a mode-1 run)
+    std::string focus;
+    std::vector<std::string> op_label;
     struct Interval { hipEvent_t e0, e1; std::string kernel; double flops, bytes; };
     std::vector<Interval> intervals;
     std::vector<hipEvent_t> event_pool;
@@ -822,7 +824,21 @@ hipEvent_t next_event(sncal_hrnet& net) {
 
 extern "C" int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_set_profiling: null");
-    net->profiling = enable != 0;
+    SNCAL_CHECK_ARG(enable >= 0 && enable <= 2, "sncal_hrnet_set_profiling: mode %d", enable);
+    if (enable == 2) {                  // focus = the kernel variant with the largest total in the profile recorded so far
+        std::map<std::string, double> tot;
+        for (const auto& iv : net->intervals) {
+            SNCAL_CHECK_HIP(hipEventSynchronize(iv.e1));
+            float ms = 0;
+            SNCAL_CHECK_HIP(hipEventElapsedTime(&ms, iv.e0, iv.e1));
+            tot[iv.kernel] += ms;
+        }
+        SNCAL_CHECK_ARG(!tot.empty(), "sncal_hrnet_set_profiling: mode 2 needs a mode-1 profile of at least one forward first");
+        net->focus.clear();
+        double best = -1;
+        for (const auto& kv : tot) if (kv.second > best) { best = kv.second; net->focus = kv.first; }
+    }
+    net->profiling = enable;
     net->intervals.clear();
     net->events_used = 0;
     return SNCAL_OK;
@@ -885,7 +901,10 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
             if (skip_next) { skip_next = false; continue; }      // second conv of a fused BasicBlock
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (net->profiling) { ev0 = next_event(*net); ev1 = next_event(*net); sncal::launch_events() = sncal::LaunchEvents{ev0, ev1}; }
+            if (net->op_label.size() != net->ops.size()) net->op_label.assign(net->ops.size(), std::string());
+            if (net->profiling == 1 || (net->profiling == 2 && net->op_label[oi] == net->focus)) {
+                ev0 = next_event(*net); ev1 = next_event(*net); sncal::launch_events() = sncal::LaunchEvents{ev0, ev1};
+            }
             switch (op.type) {
                 case OP_INPUT:
                     if (d_x8) rc = launch_u8hwc_to_nhwc(net->dtype, d_x8 + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, H, W, stream);
@@ -1021,6 +1040,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     }
                 }
                 if (op.type == OP_DECODE && (!d_kpts || decoded)) continue;
+                if (net->profiling == 1) net->op_label[oi] = net->last_kernel;
                 net->intervals.push_back({ev0, ev1, net->last_kernel, net->last_flops, net->last_bytes});
             }
         }

@@ -181,9 +181,10 @@ class HRNetHeatmap:
                        'sncal_hrnet_forward')
         return heat, kpts
 
-    def set_profiling(self, enable: bool):
-        """Record HIP events between the plan's launches (measurement only)."""
-        _lib.check(self._L.sncal_hrnet_set_profiling(self._h, 1 if enable else 0), 'set_profiling')
+    def set_profiling(self, enable):
+        """Per-launch HIP event timing (measurement only): False/0 off, True/1 every launch, 2 only the launches of
+        the kernel variant that led the profile recorded so far."""
+        _lib.check(self._L.sncal_hrnet_set_profiling(self._h, int(enable)), 'set_profiling')
 
     def get_profile(self):
         """[{kernel, flops, bytes, ms, launches}] accumulated since set_profiling(True) (synchronises)."""

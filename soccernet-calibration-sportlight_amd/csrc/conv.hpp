@@ -140,8 +140,9 @@ inline size_t conv_stage_bytes(int KS, int S, int NI, int MI, int G, int twf) {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// One work item (output tile x n-block) of a convolution; the two kernels below map workgroups to work items.
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
-__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w) {
     using frag = typename Elem<T>::frag;
     constexpr int GE = Elem<T>::GE;
     constexpr int NKG = KS * KS * G, NKS = (NKG + 3) / 4;
@@ -157,8 +158,6 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     // channel slices of the same pixels run together).  XCD-aware order: block b runs on XCD b % 8 (observed dispatch
     // rule, used for speed only), so XCD k walks the contiguous range [k, k+1) * per_xcd of work items -- neighbouring
     // tiles (shared halo rows) and the n-blocks of one tile meet in the same L2 instead of eight different ones.
-    const unsigned w = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
-    if (w >= p.n_work) return;
     unsigned tile = conv_udiv(w, (unsigned)p.nblk, p.nblk_magic);
     const int nb = (int)(w - tile * (unsigned)p.nblk);
     unsigned q = conv_udiv(tile, (unsigned)p.tiles_x, p.tiles_x_magic);
@@ -483,13 +482,55 @@ __global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kern
     }
 }
 
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kernel(const ConvParams p) {
+    const unsigned w = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
+    if (w >= p.n_work) return;
+    conv_body<T, KS, STRIDE, NI, MI, G>(p, w);
+}
+
+// Up to three INDEPENDENT convolutions of the same kernel variant in one launch (the same-depth convs of the parallel
+// HRNet branches): their work items are concatenated, so the small grids of the low-resolution branches fill the tail of
+// the big one and two launch gaps (~5 us each) disappear.  Same code per work item -> same bits.
+struct ConvGroupParams {
+    ConvParams p[3];        // members, most expensive work items first (they start first on every XCD)
+    unsigned per_xcd[3];    // ceil(n_work / 8) of each member
+    int n;
+};
+
+// Block b runs on XCD b % 8 and takes the (b / 8)-th item of that XCD's list: the XCD's contiguous slice of member 0, then
+// of member 1, then of member 2 -- every XCD gets the same mix of cheap and expensive items (a plain concatenation gave
+// whole XCDs to the 384-channel member, 3x the cost per item: 20 ms instead of 13), and each member keeps the
+// neighbouring-tiles-in-one-L2 order of the single launch.
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_group_kernel(const ConvGroupParams gp) {
+    const unsigned k = blockIdx.x & 7u;
+    unsigned j = blockIdx.x >> 3;
+    int m = 0;
+    if (j >= gp.per_xcd[0]) {
+        j -= gp.per_xcd[0]; m = 1;
+        if (gp.n < 2) return;
+        if (j >= gp.per_xcd[1]) { j -= gp.per_xcd[1]; m = 2; if (gp.n < 3 || j >= gp.per_xcd[2]) return; }
+    }
+    // member parameters by scalar selects (a dynamically indexed kernel argument would be copied to scratch)
+    ConvParams q = gp.p[0];
+    unsigned px = gp.per_xcd[0];
+    if (m == 1) { q = gp.p[1]; px = gp.per_xcd[1]; }
+    if (m == 2) { q = gp.p[2]; px = gp.per_xcd[2]; }
+    const unsigned w = k * px + j;
+    if (w >= q.n_work) return;
+    conv_body<T, KS, STRIDE, NI, MI, G>(q, w);
+}
+
 // host-visible launcher table ---------------------------------------------------------------------
 typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream_t s);
+typedef void (*ConvGroupLaunchFn)(const ConvGroupParams&, dim3 grid, size_t lds, hipStream_t s);
 
 struct ConvVariant {
     int dtype;      // SNCAL_F32 / SNCAL_BF16
     int ks, stride, ni, mi, g;
     ConvLaunchFn launch;
+    ConvGroupLaunchFn launch_group;     // nullptr: this variant has no grouped instantiation
 };
 
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
@@ -501,6 +542,24 @@ void conv_launch(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
         attr_done = true;
     }
     SNCAL_LAUNCH((conv_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, p);
+}
+
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+void conv_group_launch(const ConvGroupParams& gp, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_group_kernel<T, KS, STRIDE, NI, MI, G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    SNCAL_LAUNCH((conv_group_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, gp);
+}
+
+// grouped instantiations exist for the branch convolutions only (3x3 stride 1, 96-channel n-blocks): compile time
+template <typename T, int KS, int STRIDE, int NI, int MI, int G>
+constexpr ConvGroupLaunchFn conv_group_fn() {
+    if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MI == 6) return &conv_group_launch<T, KS, STRIDE, NI, MI, G>;
+    else return nullptr;
 }
 
 // registries filled by conv_bf16.hip / conv_f32.hip

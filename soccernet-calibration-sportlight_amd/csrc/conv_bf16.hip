@@ -4,7 +4,7 @@
 
 namespace sncal {
 static const ConvVariant k_variants_bf16[] = {
-#define V(KS, S, NI, MI, G) {SNCAL_BF16, KS, S, NI, MI, G, &conv_launch<__bf16, KS, S, NI, MI, G>},
+#define V(KS, S, NI, MI, G) {SNCAL_BF16, KS, S, NI, MI, G, &conv_launch<__bf16, KS, S, NI, MI, G>, conv_group_fn<__bf16, KS, S, NI, MI, G>()},
 #include "conv_variants.inc"
 #undef V
 };

@@ -4,7 +4,7 @@
 
 namespace sncal {
 static const ConvVariant k_variants_f32[] = {
-#define V(KS, S, NI, MI, G) {SNCAL_F32, KS, S, NI, MI, G, &conv_launch<float, KS, S, NI, MI, G>},
+#define V(KS, S, NI, MI, G) {SNCAL_F32, KS, S, NI, MI, G, &conv_launch<float, KS, S, NI, MI, G>, conv_group_fn<float, KS, S, NI, MI, G>()},
 #include "conv_variants.inc"
 #undef V
 };

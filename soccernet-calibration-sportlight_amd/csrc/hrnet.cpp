@@ -60,6 +60,7 @@ struct Op {
     int base = -1, srcs[3] = {-1, -1, -1}, nsrc = 0;
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
     int group = GRP_ALL;
+    int launch_group = -1;                // >= 0: independent convs that may share one grouped launch (consecutive ops)
     int head_direct = -1, head_src[HEAD_MAX_SRC] = {-1, -1, -1, -1, -1}, head_nsrc = 0;   // OP_HEAD
     int head_fold[HEAD_MAX_FOLD] = {-1, -1}, head_nfold = 0;                              // OP_HEAD: branches folded into stage-1 K
 };
@@ -108,6 +109,7 @@ struct sncal_hrnet {
     // profiling (sncal_hrnet_set_profiling): events recorded between launches + what each interval ran
     int profiling = 0;                    // 0 off, 1 every launch, 2 only the launches of `focus` (labels cached per op by a mode-1 run)
     std::string focus;
+    int n_launch_groups = 0;
     std::vector<std::string> op_label;
     struct Interval { hipEvent_t e0, e1; std::string kernel; double flops, bytes; };
     std::vector<Interval> intervals;
@@ -280,8 +282,27 @@ struct Builder {
             }
             for (int m = 0; m < d.num_modules[si]; ++m) {
                 const std::string mn = fmt("%sstage%d.%d", P.c_str(), si + 2, m);
+                // Branch 0 keeps block order (its conv pairs are pattern-matched into the fused BasicBlock kernel of the
+                // bf16 path).  The other branches are emitted depth-major: the same-depth convs of branches 1..nb-1 are
+                // independent and adjacent, so the executor can put them into ONE grouped launch (conv.hpp).
+                const bool group_convs = !(getenv("SNCAL_GROUP_CONVS") && atoi(getenv("SNCAL_GROUP_CONVS")) == 0);     // read per net: tests toggle it
+                bool plain = true;
                 for (int br = 0; br < nb; ++br)
-                    for (int b = 0; b < d.num_blocks[si]; ++b) xs[br] = basic_block(fmt("%s.branches.%d.%d", mn.c_str(), br, b), xs[br]);
+                    for (int b = 0; b < d.num_blocks[si]; ++b)
+                        if (net.layer_by_name.count(fmt("%s.branches.%d.%d.downsample.0", mn.c_str(), br, b))) plain = false;
+                if (group_convs && plain && nb > 2) {
+                    for (int b = 0; b < d.num_blocks[si]; ++b) xs[0] = basic_block(fmt("%s.branches.0.%d", mn.c_str(), b), xs[0]);
+                    for (int b = 0; b < d.num_blocks[si]; ++b) {
+                        std::vector<int> t(nb);
+                        const int g1 = net.n_launch_groups++;
+                        for (int br = 1; br < nb; ++br) { t[br] = conv(fmt("%s.branches.%d.%d.conv1", mn.c_str(), br, b), xs[br], true); net.ops.back().launch_group = g1; }
+                        const int g2 = net.n_launch_groups++;
+                        for (int br = 1; br < nb; ++br) { xs[br] = conv(fmt("%s.branches.%d.%d.conv2", mn.c_str(), br, b), t[br], true, xs[br]); net.ops.back().launch_group = g2; }
+                    }
+                } else {
+                    for (int br = 0; br < nb; ++br)
+                        for (int b = 0; b < d.num_blocks[si]; ++b) xs[br] = basic_block(fmt("%s.branches.%d.%d", mn.c_str(), br, b), xs[br]);
+                }
                 std::vector<int> out(nb);
                 for (int i = 0; i < nb; ++i) {                       // hrnet.py:229-244
                     int acc = xs[i];
@@ -524,6 +545,19 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         for (int s2 = 0; s2 < op.head_nfold; ++s2) use(op.head_fold[s2]);
         if (op.out >= 0) { if (T[op.out].first < 0) T[op.out].first = (int)i; T[op.out].last = std::max(T[op.out].last, (int)i); }
     }
+    {   // the members of a launch group run concurrently: a tensor one of them reads must outlive ALL of them, and their
+        // outputs must all exist from the first member on
+        std::vector<int> gfirst(net.ops.size()), glast(net.ops.size());
+        for (size_t i = 0; i < net.ops.size(); ++i) { gfirst[i] = glast[i] = (int)i; }
+        for (size_t i = 0; i < net.ops.size();) {
+            size_t j = i + 1;
+            if (net.ops[i].launch_group >= 0)
+                while (j < net.ops.size() && net.ops[j].launch_group == net.ops[i].launch_group) ++j;
+            for (size_t k = i; k < j; ++k) { gfirst[k] = (int)i; glast[k] = (int)j - 1; }
+            i = j;
+        }
+        for (Tensor& t : T) { if (t.first >= 0) t.first = gfirst[t.first]; if (t.last >= 0) t.last = glast[t.last]; }
+    }
     for (const Op& op : net.ops) {
         if (!op_active(net, op)) continue;
         switch (op.type) {
@@ -585,11 +619,11 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
     return SNCAL_OK;
 }
 
-int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t stream) {
+// parameters, kernel variant and dynamic LDS size of one convolution op (no launch)
+int prepare_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, ConvParams& p, const ConvVariant*& bestv, size_t& best_lds) {
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
-    ConvParams p;
     memset(&p, 0, sizeof(p));
     p.in = ws + ti.offset; p.out = ws + to.offset;
     p.res = op.res >= 0 ? ws + net.tensors[op.res].offset : nullptr;
@@ -599,8 +633,9 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     p.out_cstride = to.C; p.out_coff = op.out_coff;
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
     // pick NI / tile shape / sub-tiles per weight chunk for this spatial size
-    const ConvVariant* bestv = nullptr;
-    int best_twf = 1; double best_score = -1; size_t best_lds = 0;
+    bestv = nullptr;
+    best_lds = 0;
+    int best_twf = 1; double best_score = -1;
     static const int force_ni = getenv("SNCAL_FORCE_NI") ? atoi(getenv("SNCAL_FORCE_NI")) : 0;   // tuning aids
     static const double three_gain = getenv("SNCAL_THREE_GAIN") ? atof(getenv("SNCAL_THREE_GAIN")) : 1.15;
     bool has_forced = false;
@@ -658,17 +693,41 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     { static const bool dbg = getenv("SNCAL_CONV_DEBUG") != nullptr;
       if (dbg) fprintf(stderr, "[conv] %-44s %dx%d cin %d cout %d: NI%d MI%d G%d twf %d lds %zu grid %dx%d epi_lds %d\n", L.name.c_str(), to.H, to.W, L.cin, L.cout,
                        bestv->ni, L.mi, L.g, best_twf, best_lds, p.tiles_x * p.tiles_y * sb, L.nblk, p.epi_lds); }
-    // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
-    static const char* trace_name = getenv("SNCAL_CONV_TRACE");
-    unsigned long long* d_trace = nullptr; size_t n_trace = 0;
-    if (trace_name && L.name == trace_name) {
-        n_trace = (size_t)8 * ((p.tiles_x * p.tiles_y * sb * L.nblk + 7) / 8) * 16;
-        if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
-    }
     p.nblk = L.nblk;
     p.n_work = (unsigned)(p.tiles_x * p.tiles_y * sb * L.nblk);
     p.per_xcd = (p.n_work + 7) / 8;
     p.nblk_magic = conv_magic((unsigned)L.nblk); p.tiles_x_magic = conv_magic((unsigned)p.tiles_x); p.tiles_y_magic = conv_magic((unsigned)p.tiles_y);
+    return SNCAL_OK;
+}
+
+void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVariant* bestv, bool add) {
+    const ConvLayer& L = net.layers[op.conv];
+    const Tensor& ti = net.tensors[op.in];
+    const Tensor& to = net.tensors[op.out];
+    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride, bestv->ni, L.mi, L.g);
+    static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
+    if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
+    const double px = (double)sb * to.H * to.W;
+    if (!add) { net.last_flops = 0; net.last_bytes = 0; }
+    net.last_flops += 2.0 * px * L.cout * L.cin * L.k * L.k;
+    net.last_bytes += (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +
+                      (double)L.cout * L.cin * L.k * L.k * net.esize;
+}
+
+int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t stream) {
+    const ConvLayer& L = net.layers[op.conv];
+    ConvParams p;
+    const ConvVariant* bestv = nullptr;
+    size_t best_lds = 0;
+    const int rc = prepare_conv(net, op, sb, ws, p, bestv, best_lds);
+    if (rc) return rc;
+    // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
+    static const char* trace_name = getenv("SNCAL_CONV_TRACE");
+    unsigned long long* d_trace = nullptr; size_t n_trace = 0;
+    if (trace_name && L.name == trace_name) {
+        n_trace = (size_t)8 * ((p.n_work + 7) / 8) * 16;
+        if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
+    }
     bestv->launch(p, dim3(8 * p.per_xcd), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
@@ -678,16 +737,44 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         (void)hipFree(d_trace);
         if (FILE* f = fopen(getenv("SNCAL_CONV_TRACE_FILE") ? getenv("SNCAL_CONV_TRACE_FILE") : "conv_trace.bin", "wb")) { fwrite(h.data(), 8, n_trace, f); fclose(f); }
     }
-    if (net.profiling) {
-        net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride,
-                              bestv->ni, L.mi, L.g);
-        static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
-        if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
-        const double px = (double)sb * to.H * to.W;
-        net.last_flops = 2.0 * px * L.cout * L.cin * L.k * L.k;
-        net.last_bytes = (double)sb * ti.H * ti.W * ti.C * net.esize + px * L.cout * (op.out_f32 ? 4 : net.esize) * (op.res >= 0 ? 2 : 1) +
-                         (double)L.cout * L.cin * L.k * L.k * net.esize;
+    if (net.profiling) conv_profile_entry(net, op, sb, bestv, false);
+    return SNCAL_OK;
+}
+
+// the members of a launch group (independent convs, consecutive ops): one grouped launch when they agree on the kernel
+// variant and that variant has a grouped instantiation; otherwise *done = false and the caller runs them one by one
+int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hipStream_t stream, bool* done) {
+    *done = false;
+    if (n < 2 || n > 3) return SNCAL_OK;
+    ConvGroupParams gp;
+    memset(&gp, 0, sizeof(gp));
+    const ConvVariant* v0 = nullptr;
+    size_t lds = 0;
+    ConvParams mp[3];
+    double cost[3];
+    for (int i = 0; i < n; ++i) {
+        const ConvVariant* v = nullptr;
+        size_t l = 0;
+        const int rc = prepare_conv(net, ops[i], sb, ws, mp[i], v, l);
+        if (rc) return rc;
+        if (i == 0) v0 = v;
+        if (v != v0 || !v->launch_group) return SNCAL_OK;
+        lds = std::max(lds, l);
+        cost[i] = (double)net.layers[ops[i].conv].chunks;            // K-chunks per work item
     }
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + n, [&](int a, int b) { return cost[a] > cost[b]; });      // longest items first
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        gp.p[i] = mp[order[i]];
+        gp.per_xcd[i] = (gp.p[i].n_work + 7) / 8;
+        blocks += gp.per_xcd[i];
+    }
+    gp.n = n;
+    v0->launch_group(gp, dim3(8 * blocks), lds, stream);
+    SNCAL_CHECK_LAUNCH();
+    if (net.profiling) for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, v0, i > 0);
+    *done = true;
     return SNCAL_OK;
 }
 
@@ -895,10 +982,12 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
         const int sb = std::min(SB, B - b0);
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
         bool skip_next = false, decoded = false;
+        int skip_group = 0;                                  // remaining members of a launch group that already ran
         for (size_t oi = 0; oi < net->ops.size(); ++oi) {
             const Op& op = net->ops[oi];
             if (!op_active(*net, op)) continue;
             if (skip_next) { skip_next = false; continue; }      // second conv of a fused BasicBlock
+            if (skip_group > 0) { --skip_group; continue; }
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (net->op_label.size() != net->ops.size()) net->op_label.assign(net->ops.size(), std::string());
@@ -911,6 +1000,15 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     else rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
                     break;
                 case OP_CONV: {
+                    if (op.launch_group >= 0) {              // same-depth convs of the parallel branches: one grouped launch
+                        int n = 1;
+                        while (oi + n < net->ops.size() && net->ops[oi + n].launch_group == op.launch_group && net->ops[oi + n].type == OP_CONV &&
+                               op_active(*net, net->ops[oi + n])) ++n;
+                        bool done = false;
+                        rc = run_conv_group(*net, &net->ops[oi], n, sb, ws, stream, &done);
+                        if (rc) return rc;
+                        if (done) { skip_group = n - 1; break; }
+                    }
                     // BasicBlock of the 48-channel branch: conv1 + conv2 (+ residual) fused when the next active op
                     // is its second convolution and both layers carry the (MI = 3, G = 3) packing
                     const Op* op2 = nullptr;

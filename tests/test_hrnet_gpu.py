@@ -166,3 +166,26 @@ def test_fused_logsoftmax_decode_is_bit_identical(sncal, cuda, cfg_name, hw):
     assert torch.equal(k_fused, k_heat)
     ref = od.keypoint_decode(heat.cpu().numpy(), (540, 960))
     assert np.array_equal(k_fused.cpu().numpy()[..., :2], ref[..., :2])
+
+
+def test_grouped_branch_convs_are_bit_identical(sncal, cuda, monkeypatch):
+    """The same-depth 3x3 convs of branches 1..3 share one grouped launch (conv.hpp conv_group_kernel; plan emitted
+    depth-major, workspace lifetimes widened to the group).  Same code per work item: the bf16 network output must not
+    change by one bit against the one-launch-per-conv plan, and the launch count of the dominant variant drops."""
+    cfg = hr.load_config('hrnet_w48')
+    sd = hr.seeded_state_dict(cfg, 2, 1.5)
+    x = hr.seeded_input(2, 540, 960, 9).to(cuda)
+    outs, launches = [], []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SNCAL_GROUP_CONVS', flag)
+        net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+        net.load_state_dict(sd)
+        net.set_profiling(True)
+        heat, _ = net.forward(x, want_heat=True)
+        prof = {p['kernel']: p for p in net.get_profile()}
+        launches.append(prof['conv<bf16,k3,s1,NI3,MI6,G4>']['launches'])
+        outs.append(heat.clone())
+        flops = sum(p['flops'] for p in prof.values())
+        assert abs(flops / (2 * 2 * 253910384640) - 1) < 0.3          # accounting still covers every conv (2 frames; fused head counts fewer)
+    assert torch.equal(outs[0], outs[1])
+    assert launches[0] < launches[1], launches

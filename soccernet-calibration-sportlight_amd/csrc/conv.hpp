@@ -555,10 +555,12 @@ void conv_group_launch(const ConvGroupParams& gp, dim3 grid, size_t lds, hipStre
     SNCAL_LAUNCH((conv_group_kernel<T, KS, STRIDE, NI, MI, G>), grid, dim3(256), lds, s, gp);
 }
 
-// grouped instantiations exist for the branch convolutions only (3x3 stride 1, 96-channel n-blocks): compile time
+// grouped instantiations exist for the branch convolutions (3x3 stride 1, 96-channel n-blocks) and the fuse-up 1x1 convs
+// only: compile time
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
 constexpr ConvGroupLaunchFn conv_group_fn() {
-    if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && MI == 6) return &conv_group_launch<T, KS, STRIDE, NI, MI, G>;
+    if constexpr (sizeof(T) == 2 && STRIDE == 1 && ((KS == 3 && MI == 6) || (KS == 1 && G == 8 && (MI == 3 || MI == 6))))
+        return &conv_group_launch<T, KS, STRIDE, NI, MI, G>;
     else return nullptr;
 }
 

@@ -318,7 +318,12 @@ struct Builder {
                     }
                     if (has_up) {
                         std::vector<int> ups;
-                        for (int j = i + 1; j < nb; ++j) ups.push_back(conv(fmt("%s.fuse_layers.%d.%d.0", mn.c_str(), i, j), xs[j], false));
+                        const bool grp = !(getenv("SNCAL_GROUP_CONVS") && atoi(getenv("SNCAL_GROUP_CONVS")) == 0) && nb - i - 1 >= 2;
+                        const int gid = grp ? net.n_launch_groups++ : -1;      // the 1x1 convs of one fuse-up sum are independent
+                        for (int j = i + 1; j < nb; ++j) {
+                            ups.push_back(conv(fmt("%s.fuse_layers.%d.%d.0", mn.c_str(), i, j), xs[j], false));
+                            net.ops.back().launch_group = gid;
+                        }
                         acc = upadd(acc, ups, true, net.tensors[xs[i]].C);
                     }
                     out[i] = acc;

@@ -6,10 +6,10 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        m = re.search(r'conv_kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
+        m = re.search(r'conv_(?:group_)?kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
         if m: k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
         else:
-            m2 = re.search(r'conv_kernel<.*?(\d), (\d), (\d), (\d)>', k)
+            m2 = re.search(r'conv_(?:group_)?kernel<.*?(\d), (\d), (\d), (\d)>', k)
             k = 'conv<NI%s,MI%s,G%s>' % m2.groups()[:3] if m2 else ('head_fused' if 'head_fused' in k else k[:48])
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         key = (r['Dispatch_Id'], k)

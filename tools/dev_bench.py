@@ -4,14 +4,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import sncal_amd
-from oracle import hrnet_ref as hr
+from bench import seeded_weights     # the bench's own weight generator: measurement scripts never import oracle/
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dtype = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device('cuda:0')
-cfg = hr.load_config('hrnet_w48')
 net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
-net.load_state_dict(hr.seeded_state_dict(cfg, 1, 1.5))
+net.load_state_dict(seeded_weights('hrnet_w48', 1))
 x = torch.rand((B, 3, 540, 960), device=dev)
 for _ in range(1):
     net.forward(x, want_heat=False, decode_size=(540, 960))

@@ -189,3 +189,22 @@ def test_grouped_branch_convs_are_bit_identical(sncal, cuda, monkeypatch):
         assert abs(flops / (2 * 2 * 253910384640) - 1) < 0.3          # accounting still covers every conv (2 frames; fused head counts fewer)
     assert torch.equal(outs[0], outs[1])
     assert launches[0] < launches[1], launches
+
+
+def test_frames_are_independent_of_batch_size_and_position(sncal, cuda):
+    """Size-independent property at the bench configuration (W48, 960x540, bf16): a frame's keypoints and heatmap do not
+    depend on the batch it travels in -- different batch sizes pick different tile shapes, grid orders and grouped
+    launches, and a 67-frame batch crosses the 64-frame sub-batch boundary -- because every output element is accumulated
+    in a fixed order."""
+    cfg = hr.load_config('hrnet_w48')
+    net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 1, 1.5))
+    x = torch.rand((67, 3, 540, 960), device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    _, k_all = net.forward(x, want_heat=False, decode_size=(540, 960))
+    k_all = k_all.clone()
+    for lo, hi in ((0, 1), (1, 4), (60, 67), (10, 41)):
+        _, k = net.forward(x[lo:hi].contiguous(), want_heat=False, decode_size=(540, 960))
+        assert torch.equal(k, k_all[lo:hi]), (lo, hi)
+    h3, _ = net.forward(x[:3].contiguous(), want_heat=True)
+    h2, _ = net.forward(x[:2].contiguous(), want_heat=True)
+    assert torch.equal(h3[:2], h2)

@@ -177,3 +177,43 @@ def test_argument_validation_and_empty_batches_without_a_gpu():
     h = ctypes.c_void_p()
     assert lib.sncal_hrnet_create(ctypes.byref(desc), 1, ctypes.byref(h)) == ERR_ARG               # zeroed descriptor
     assert lib.sncal_hrnet_forward(None, None, 1, 540, 960, None, None, 540, 960, None, 0, None) == ERR_ARG
+
+
+def test_jpeg_host_parser_survives_damaged_streams():
+    """The JPEG host stage parses untrusted bytes: 600 mutations of golden streams (bit flips, truncations, spliced
+    segments, oversized dimensions) must each come back with a status -- OK or a documented error -- and never read or
+    write out of bounds (the coefficient buffer carries guard words)."""
+    import sncal_amd
+    L = sncal_amd._lib
+    lib = L.lib()
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'jpeg_cases.npz'))
+    names = [str(n) for n in g['names']]
+    rng = np.random.default_rng(11)
+    seen = set()
+    for it in range(600):
+        src = bytearray(g['jpg.' + names[int(rng.integers(len(names)))]].tobytes())
+        kind = it % 4
+        if kind == 0:                                        # random bit flips anywhere (headers included)
+            for _ in range(int(rng.integers(1, 6))):
+                src[int(rng.integers(len(src)))] ^= 1 << int(rng.integers(8))
+        elif kind == 1:                                      # truncation
+            src = src[:int(rng.integers(2, len(src)))]
+        elif kind == 2:                                      # a chunk of the stream overwritten by another part of it
+            a, b, n = (int(rng.integers(len(src))) for _ in range(3))
+            n = min(n % 64 + 1, len(src) - max(a, b))
+            src[a:a + n] = src[b:b + n]
+        else:                                                # frame header: dimensions / sampling factors / component count
+            sof = bytes(src).find(b'\xff\xc0')
+            if sof >= 0:
+                src[sof + 5 + int(rng.integers(0, 12))] = int(rng.integers(256))
+        data = bytes(src)
+        info = L.JpegInfo()
+        st = lib.sncal_jpeg_probe(data, len(data), ctypes.byref(info))
+        assert st in (0, -1, -5), st
+        cap = 1 << 16                                        # small on purpose: big frames must be refused with -4
+        buf = np.full(cap + 64, 0x5A5A, np.int16)
+        st2 = lib.sncal_jpeg_entropy_decode(data, len(data), buf.ctypes.data, cap, ctypes.byref(info))
+        assert st2 in (0, -1, -4, -5), st2
+        assert (buf[cap:] == 0x5A5A).all()
+        seen.add(st2)
+    assert {0, -1} <= seen

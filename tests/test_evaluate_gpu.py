@@ -116,3 +116,42 @@ def test_evaluator_matches_oracle_on_random_cameras(sncal, cuda):
     assert bad == 0, f'{bad} of 64 frames differ from the oracle'
     accs = np.where(out[:, 10] == 1, out[:, 8], out[:, 9])
     assert np.allclose(accs, [a for _, a, _, _ in expect], rtol=1e-6) and 0.1 < accs.mean() < 0.99
+
+
+def test_solved_cameras_score_on_the_benchmark_metric(sncal, cuda):
+    """The chain the reference runs across three scripts (predict -> CameraCreator -> evaluate_camera.py), on the device
+    end to end: 48 synthetic cameras -> noisy template keypoints -> sncal_calibrate -> sncal_evaluate_cameras against
+    annotations sampled from the TRUE cameras' pitch polylines.  With 1 px keypoint noise the solved cameras must
+    reproduce the true polylines within the benchmark's 5 px on nearly every class (mean accuracy@5 > 0.9), and the
+    oracle's metric of the same solved cameras must agree with the kernel's."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    table = oe.field_table()
+    kps, ann = [], []
+    while len(kps) < 48:
+        cam = sncal.synth.random_camera(rng)
+        kp = sncal.synth.keypoints_for_camera(cam, rng, sigma_px=1.0, outlier_frac=0.0)
+        if (kp[:, 2] > 0.5).sum() < 14:
+            continue
+        true_poly = oe.get_polylines(np.asarray(cam.position), np.asarray(cam.rotation), cam.xfocal_length, cam.yfocal_length,
+                                     (480., 270.), 960, 540, table)
+        if len(true_poly) < 4:
+            continue
+        kps.append(kp)
+        ann.append({c: [tuple(p) for p in v[::max(1, len(v) // 6)][:8]] for c, v in true_poly.items()})
+    cc = sncal.submit.default_calibrator()
+    rec = cc.solve_device(torch.from_numpy(np.stack(kps)).to(cuda))
+    ev = sncal.CameraEvaluator(cuda, 960, 540, threshold=5)
+    out = ev.evaluate(rec, ann).cpu().numpy()
+    s = sncal.CameraEvaluator.summarize(out)
+    assert s['completeness'] > 0.95 and s['accuracy'] > 0.9, s
+    # the oracle's metric on the same solved cameras
+    cams = [sncal.prediction.camera_from_record(r, cc.img_size) for r in cc.records(rec)]
+    agree = 0
+    for i, c in enumerate(cams):
+        if c is None:
+            assert out[i, 11] == 0
+            continue
+        conf, acc, c1, c2 = oe.evaluate_frame(np.asarray(c.position), np.asarray(c.rotation), c.xfocal_length, c.yfocal_length,
+                                              (480., 270.), ann[i], 5, table=table)
+        agree += int(np.array_equal(out[i, 0:4], c1.reshape(-1)) and np.array_equal(out[i, 4:8], c2.reshape(-1)))
+    assert agree >= len([c for c in cams if c is not None]) - 1        # a distance within rounding of the threshold may flip one class

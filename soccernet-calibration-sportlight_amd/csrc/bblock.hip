@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256, 2) void bblock48_kernel(const BBlockParams p) 
                                                      (unsigned)(chunk * BB_WBYTES + i * 1024), 0, 0);
     };
     issue_w(rs_w1, s_w, 0);
-    issue_w(rs_w1, s_mid, 1);                    // conv1's second chunk waits in the (still unused) mid region
     // x halo, row-aligned: a halo row (18 pixels x 7 slots = 126 slots) is two 64-slot DMA pieces, so a lane's part of
     // the address (pixel-in-row, k-group, left/right bounds) is the same for every row and the row rides in the scalar
     // offset -- no per-piece VALU work.  Slot 6, slots 126/127 and outside-image pixels read out of range -> zeros.
@@ -86,6 +85,9 @@ __global__ __launch_bounds__(256, 2) void bblock48_kernel(const BBlockParams p) 
         const unsigned voff = rowok ? ((j & 1) ? xv[1] : xv[0]) : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(s_x + j * 1024), 16, voff, rowok ? (unsigned)(iy * p.W * 96) : 0u, 0, 0);
     }
+    // conv1's second chunk goes LAST, into the (still unused) mid region: the first MFMA phase only waits for what was
+    // issued before it (loads complete in order; wave 0 owns 6 of the 21 pieces, the others 5) and W1c1 lands under it
+    issue_w(rs_w1, s_mid, 1);
 
     // fragment offsets of k-step s within a 24-channel chunk: k-group kg = 4s + g -> (tap, cg); same order as pack_layer
     auto frag_off = [&](int s, int row_pitch, int chunk) -> int {
@@ -148,11 +150,14 @@ __global__ __launch_bounds__(256, 2) void bblock48_kernel(const BBlockParams p) 
         boff2[j] = (r * BB_MW + c) * BB_PS;
     }
     init_acc(p.b1);
-    round_done();                                // x halo, W1c0, W1c1 landed
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // my x-halo and W1c0 pieces landed
+    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");      // ... everyone's
     stamp(2);
     mma_chunk(s_w, s_x, boff1, BB_XROW, 0, 4);
     stamp(3);
-    asm volatile("s_barrier" ::: "memory");      // everyone finished reading W1c0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my W1c1 pieces landed
+    asm volatile("s_barrier" ::: "memory");      // everyone's did, and everyone finished reading W1c0
     issue_w(rs_w2, s_w, 0);                      // conv2's first chunk lands under conv1's second
     stamp(4);
     mma_chunk(s_mid, s_x, boff1, BB_XROW, 1, 4);

@@ -40,6 +40,11 @@
 // buffers with two or three workgroups per CU, so the kernel keeps single buffers only.  An L2 prefetch of a future
 // workgroup's halo (one dword per 128-byte line through LDS-DMA, issued under the last MFMA phase) left the first
 // round's wait unchanged: that wait is the prologue's own VALU work and DMA issue, not a cold-miss latency.
+// Progressive landing (halo first, weights in k-step order, the MFMAs of k-steps 0..2 starting when the first third of the
+// weights has landed: partial s_waitcnt vmcnt(N) + two extra barriers per chunk) was also built: bit-identical, the explicit
+// wait fell from 1.4k to 0.2k clk but the ISSUE phase grew by the same amount -- the issuing waves are throttled by the CU's
+// LDS-DMA rate (75 KB per chunk at <= 58 B/clk/CU; 54 KB of it weights re-fetched per 192-pixel tile), so a round is bound
+// by DMA throughput during its burst rather than by the latency of its last piece; workgroup lifetime unchanged, removed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

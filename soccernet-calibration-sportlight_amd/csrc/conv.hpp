@@ -438,7 +438,14 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                             }
                             bf16x8 q;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) q[e] = (__bf16)(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                            for (int e = 0; e < 8; ++e) q[e] = (__bf16)v[e];
+                            if (p.relu) {
+                                // ReLU on the packed bf16 pairs: rounding keeps the sign, so relu(round(x)) == round(relu(x)); a bf16
+                                // with the sign bit set is a negative int16 -> v_pk_max_i16 against 0, one instruction per two values
+                                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                                const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                                q = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), zero));
+                            }
                             *reinterpret_cast<bf16x8*>(out_img + off[j0 + jj][it]) = q;
                         }
                     }

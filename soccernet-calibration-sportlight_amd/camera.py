@@ -1,44 +1,61 @@
-"""Camera model -- host mirror of /root/reference/baseline/camera.py:77-426 (class Camera).
+"""Camera model behind the reference's ``baseline.camera.Camera`` surface (/root/reference/baseline/camera.py:77-426).
 
-Same public attributes (position, rotation, calibration, radial_distortion, thin_prism_disto, tangential_disto,
-image_width, image_height, xfocal_length, yfocal_length, principal_point) and methods (solve_pnp,
-refine_camera, from_homography, to_json_parameters, from_json_parameters, distort, project_point,
-projection_rmse, scale_resolution, estimate_calibration_matrix_from_plane_homography).  Plain numpy arrays,
-mutated in place, picklable.  The two optimisation entry points (solve_pnp, refine_camera) run on the GPU
-through libsncal.so (csrc/solve.hip); everything else is small fp64 host arithmetic.  draw_* (visualisation)
-is out of scope.
+Public attributes (position, rotation, calibration, radial_distortion, thin_prism_disto, tangential_disto,
+image_width, image_height, xfocal_length, yfocal_length, principal_point), method names, argument meaning and
+the ten JSON keys are the reference's -- that is the API ``make_submit.py`` / ``evaluate_camera.py`` bind to.
+The arithmetic underneath is this build's own:
+
+* projection is vectorised over an (N,3) block of world points (``project_points``); ``project_point`` is its
+  one-row form.  It keeps the reference's observable numerics: the z <= 1e-3 cut, and the float32 round trip of
+  the normalised image coordinates that ``distort`` performs (camera.py:247) before the focal length is applied;
+* the intrinsics from one plane homography use the image-of-the-absolute-conic constraints in closed form: with
+  zero skew, square pixels and the principal-point direction fixed, omega has three unknowns and the two
+  homography constraints give its null direction as a cross product -- no SVD, and the Cholesky factor of a
+  matrix with this sparsity is three square roots;
+* pan / tilt / roll are the ZXZ Euler angles of rotation^T, both tilt branches evaluated, the branch with the
+  smaller |roll| kept (the reference's selection rule, camera.py:56-58).
+
+``solve_pnp`` / ``refine_camera`` run on the GPU through libsncal.so (csrc/solve.hip).  Pinned by
+tests/golden/camera.npz (captured from the imported reference).  ``draw_*`` is out of scope.
 """
 import numpy as np
 
 from . import _lib
 
 
+def _rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def _rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]])
+
+
 def pan_tilt_roll_to_orientation(pan, tilt, roll):
-    Rpan = np.array([[np.cos(pan), -np.sin(pan), 0], [np.sin(pan), np.cos(pan), 0], [0, 0, 1]])
-    Rroll = np.array([[np.cos(roll), -np.sin(roll), 0], [np.sin(roll), np.cos(roll), 0], [0, 0, 1]])
-    Rtilt = np.array([[1, 0, 0], [0, np.cos(tilt), -np.sin(tilt)], [0, np.sin(tilt), np.cos(tilt)]])
-    return np.dot(Rpan, np.dot(Rtilt, Rroll))
+    """Orientation = Rz(pan) . Rx(tilt) . Rz(roll)   (camera.py:7-28; the camera's rotation is its transpose)."""
+    return _rot_z(pan) @ (_rot_x(tilt) @ _rot_z(roll))
 
 
 def rotation_matrix_to_pan_tilt_roll(rotation):
-    """ZXZ Euler decomposition; of the two solutions the one with the smaller |roll| (camera.py:31-58)."""
-    orientation = np.transpose(rotation)
-    first_tilt = np.arccos(orientation[2, 2])
-    second_tilt = -first_tilt
-    s1 = 1. if np.sin(first_tilt) > 0. else -1.
-    s2 = 1. if np.sin(second_tilt) > 0. else -1.
-    first_pan = np.arctan2(s1 * orientation[0, 2], s1 * -orientation[1, 2])
-    second_pan = np.arctan2(s2 * orientation[0, 2], s2 * -orientation[1, 2])
-    first_roll = np.arctan2(s1 * orientation[2, 0], s1 * orientation[2, 1])
-    second_roll = np.arctan2(s2 * orientation[2, 0], s2 * orientation[2, 1])
-    if np.fabs(first_roll) < np.fabs(second_roll):
-        return first_pan, first_tilt, first_roll
-    return second_pan, second_tilt, second_roll
+    """Inverse of the above.  cos(tilt) = O[2,2] leaves tilt = +-acos; each sign fixes pan and roll through the
+    last column / last row of O.  Returns the branch with the smaller |roll| (ties: the negative-tilt one)."""
+    O = np.asarray(rotation).T
+    t_pos = np.arccos(O[2, 2])
+    branches = []
+    for tilt in (t_pos, -t_pos):
+        sg = 1.0 if np.sin(tilt) > 0.0 else -1.0
+        pan = np.arctan2(sg * O[0, 2], sg * -O[1, 2])
+        roll = np.arctan2(sg * O[2, 0], sg * O[2, 1])
+        branches.append((pan, tilt, roll))
+    first, second = branches
+    return first if np.fabs(first[2]) < np.fabs(second[2]) else second
 
 
 def unproject_image_point(homography, point2D):
-    pitchpoint = np.linalg.inv(homography) @ point2D
-    return pitchpoint / pitchpoint[2]
+    q = np.linalg.solve(np.asarray(homography, dtype=np.float64), np.asarray(point2D, dtype=np.float64))
+    return q / q[2]
 
 
 def _gpu_pnp(mode, calibration, rotation, position, point_matches, max_iters=0, eps=0.0):
@@ -77,17 +94,18 @@ def _gpu_pnp(mode, calibration, rotation, position, point_matches, max_iters=0, 
 
 class Camera:
     def __init__(self, iwidth=960, iheight=540):
-        self.position = np.zeros(3)
-        self.rotation = np.eye(3)
-        self.calibration = np.eye(3)
-        self.radial_distortion = np.zeros(6)
-        self.thin_prism_disto = np.zeros(4)
-        self.tangential_disto = np.zeros(2)
-        self.image_width = iwidth
-        self.image_height = iheight
-        self.xfocal_length = 1
-        self.yfocal_length = 1
-        self.principal_point = (self.image_width / 2, self.image_height / 2)
+        self.image_width, self.image_height = iwidth, iheight
+        self.position, self.rotation, self.calibration = np.zeros(3), np.eye(3), np.eye(3)
+        for name, size in (('radial_distortion', 6), ('thin_prism_disto', 4), ('tangential_disto', 2)):
+            setattr(self, name, np.zeros(size))
+        self.xfocal_length = self.yfocal_length = 1
+        self.principal_point = (iwidth / 2, iheight / 2)
+
+    def _set_intrinsics(self, fx, fy, pp):
+        self.xfocal_length, self.yfocal_length, self.principal_point = fx, fy, pp
+        K = np.eye(3)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, pp[0], pp[1]
+        self.calibration = K
 
     # ---- GPU-backed optimisation (S6, S7) -----------------------------------------------------------
     def solve_pnp(self, point_matches):
@@ -102,127 +120,112 @@ class Camera:
         R, pos, _ = _gpu_pnp(0, self.calibration, self.rotation, self.position, pointMatches)
         self.rotation, self.position = R, pos
 
-    # ---- host arithmetic --------------------------------------------------------------------------------
+    # ---- intrinsics / pose from a ground-plane homography (camera.py:121-154, 366-426) ---------------------
+    def estimate_calibration_matrix_from_plane_homography(self, homography):
+        """K from H = K [r1 r2 t].  omega = K^-T K^-1 restricted to zero skew (w01 = 0), square pixels (w00 = w11)
+        and a principal point on the line through (cx, cy) (w12 = (cy/cx) w02) is  a*diag(1,1,0) + d*S + e*E33  with
+        S the symmetric matrix carrying (1, cy/cx) in its last row/column.  r1 . r2 = 0 and |r1| = |r2| are two linear
+        equations in (a, d, e); their solution is the cross product of the coefficient rows."""
+        Hm = np.asarray(homography, dtype=np.float64).reshape(3, 3)
+        h1, h2 = Hm[:, 0], Hm[:, 1]
+        ratio = self.principal_point[1] / self.principal_point[0]
+
+        def coeffs(u, v):     # u^T omega v as a row over (a, d, e)
+            return np.array([u[0] * v[0] + u[1] * v[1],
+                             u[0] * v[2] + u[2] * v[0] + ratio * (u[1] * v[2] + u[2] * v[1]),
+                             u[2] * v[2]])
+        a, d, e = np.cross(coeffs(h1, h2), coeffs(h1, h1) - coeffs(h2, h2))
+        if e == 0.0 or not np.isfinite(a / e) or not np.isfinite(d / e):
+            return False, np.eye(3)
+        A, D = a / e, d / e
+        # Cholesky of [[A,0,D],[0,A,rD],[D,rD,1]]: l00 = l11 = sqrt(A), l20 = D/l00, l21 = rD/l11, l22^2 = 1 - l20^2 - l21^2
+        rem = 1.0 - (D * D) * (1.0 + ratio * ratio) / A if A > 0.0 else -1.0
+        if not (A > 0.0 and rem > 0.0):
+            return False, np.eye(3)          # omega is not positive definite: no real camera behind this homography
+        focal = np.sqrt(rem / A)             # (K^-T)^-1 normalised to K[2,2] = 1: K00 = K11 = l22 / l00
+        K = np.array([[focal, 0.0, -D / A], [0.0, focal, -ratio * D / A], [0.0, 0.0, 1.0]])
+        self._set_intrinsics(K[0, 0], K[1, 1], (self.image_width / 2, self.image_height / 2))
+        return True, K
+
     def from_homography(self, homography):
-        success, _ = self.estimate_calibration_matrix_from_plane_homography(homography)
-        if not success:
+        ok, _ = self.estimate_calibration_matrix_from_plane_homography(homography)
+        if not ok:
             return False
-        hprim = np.linalg.inv(self.calibration) @ homography
-        lambda1 = 1 / np.linalg.norm(hprim[:, 0])
-        lambda2 = 1 / np.linalg.norm(hprim[:, 1])
-        lambda3 = np.sqrt(lambda1 * lambda2)
-        r0 = hprim[:, 0] * lambda1
-        r1 = hprim[:, 1] * lambda2
-        R = np.column_stack((r0, r1, np.cross(r0, r1)))
-        u, s, vh = np.linalg.svd(R)
-        R = u @ vh
-        if np.linalg.det(R) < 0:
-            u[:, 2] *= -1
-            R = u @ vh
-        self.rotation = R
-        self.position = -np.transpose(R) @ (hprim[:, 2] * lambda3)
+        M = np.linalg.inv(self.calibration) @ np.asarray(homography, dtype=np.float64)
+        s1, s2 = 1.0 / np.linalg.norm(M[:, 0]), 1.0 / np.linalg.norm(M[:, 1])
+        c1, c2 = M[:, 0] * s1, M[:, 1] * s2
+        # nearest rotation to [c1 c2 c1xc2] in the Frobenius sense
+        U, _, Vt = np.linalg.svd(np.stack([c1, c2, np.cross(c1, c2)], axis=1))
+        if np.linalg.det(U @ Vt) < 0:
+            U[:, 2] = -U[:, 2]
+        self.rotation = U @ Vt
+        self.position = -(self.rotation.T @ (M[:, 2] * np.sqrt(s1 * s2)))
         return True
 
+    # ---- JSON (camera.py:156-218; the 10 keys and their order are the file format) ----------------------------
     def to_json_parameters(self):
-        pan, tilt, roll = rotation_matrix_to_pan_tilt_roll(self.rotation)
-        return {
-            "pan_degrees": pan * 180. / np.pi,
-            "tilt_degrees": tilt * 180. / np.pi,
-            "roll_degrees": roll * 180. / np.pi,
-            "position_meters": self.position.tolist(),
-            "x_focal_length": self.xfocal_length,
-            "y_focal_length": self.yfocal_length,
-            "principal_point": [self.principal_point[0], self.principal_point[1]],
-            "radial_distortion": self.radial_distortion.tolist(),
-            "tangential_distortion": self.tangential_disto.tolist(),
-            "thin_prism_distortion": self.thin_prism_disto.tolist(),
-        }
+        angles = [a * 180. / np.pi for a in rotation_matrix_to_pan_tilt_roll(self.rotation)]
+        fields = list(zip(("pan_degrees", "tilt_degrees", "roll_degrees"), angles))
+        fields += [("position_meters", self.position.tolist()),
+                   ("x_focal_length", self.xfocal_length), ("y_focal_length", self.yfocal_length),
+                   ("principal_point", [self.principal_point[0], self.principal_point[1]])]
+        fields += [(key, getattr(self, attr).tolist()) for key, attr in (("radial_distortion", "radial_distortion"),
+                   ("tangential_distortion", "tangential_disto"), ("thin_prism_distortion", "thin_prism_disto"))]
+        return dict(fields)          # insertion order = the reference's key order (camera.py:162-173)
 
     def from_json_parameters(self, calib_json_object):
-        self.principal_point = calib_json_object["principal_point"]
-        self.image_width = 2 * self.principal_point[0]
-        self.image_height = 2 * self.principal_point[1]
-        self.xfocal_length = calib_json_object["x_focal_length"]
-        self.yfocal_length = calib_json_object["y_focal_length"]
-        self.calibration = np.array([[self.xfocal_length, 0, self.principal_point[0]],
-                                     [0, self.yfocal_length, self.principal_point[1]], [0, 0, 1]], dtype='float')
-        pan = calib_json_object['pan_degrees'] * np.pi / 180.
-        tilt = calib_json_object['tilt_degrees'] * np.pi / 180.
-        roll = calib_json_object['roll_degrees'] * np.pi / 180.
-        self.rotation = np.transpose(pan_tilt_roll_to_orientation(pan, tilt, roll))
-        self.position = np.array(calib_json_object['position_meters'], dtype='float')
-        self.radial_distortion = np.array(calib_json_object['radial_distortion'], dtype='float')
-        self.tangential_disto = np.array(calib_json_object['tangential_distortion'], dtype='float')
-        self.thin_prism_disto = np.array(calib_json_object['thin_prism_distortion'], dtype='float')
+        js = calib_json_object
+        pp = js["principal_point"]
+        self.image_width, self.image_height = 2 * pp[0], 2 * pp[1]
+        self._set_intrinsics(js["x_focal_length"], js["y_focal_length"], pp)
+        angles = [js[k] * np.pi / 180. for k in ("pan_degrees", "tilt_degrees", "roll_degrees")]
+        self.rotation = pan_tilt_roll_to_orientation(*angles).T
+        for attr, key in (("position", "position_meters"), ("radial_distortion", "radial_distortion"),
+                          ("tangential_disto", "tangential_distortion"), ("thin_prism_disto", "thin_prism_distortion")):
+            setattr(self, attr, np.array(js[key], dtype='float'))
+
+    # ---- projection (camera.py:220-277) ------------------------------------------------------------------
+    def _distort_block(self, xy):
+        """(N,2) float64 normalised coordinates -> (N,2) float32: rational radial + tangential + thin-prism model."""
+        x, y = xy[:, 0], xy[:, 1]
+        r = np.sqrt(x * x + y * y)
+        pw = np.stack([r ** 2, r ** 4, r ** 6], axis=0)                     # (3,N)
+        k = self.radial_distortion
+        gain = (1 + k[:3] @ pw) / (1 + k[3:6] @ pw)
+        p1, p2 = self.tangential_disto
+        s = self.thin_prism_disto
+        xd = x * gain + 2 * p1 * x * y + p2 * (pw[0] + 2 * x ** 2) + s[0] * pw[0] + s[1] * pw[1]
+        yd = y * gain + 2 * p2 * x * y + p1 * (pw[0] + 2 * y ** 2) + s[2] * pw[0] + s[3] * pw[1]
+        return np.stack([xd, yd], axis=1).astype(np.float32)               # the reference returns float32 (:247)
 
     def distort(self, point):
-        numerator = 1
-        denominator = 1
-        radius = np.sqrt(point[0] * point[0] + point[1] * point[1])
-        for i in range(3):
-            numerator += self.radial_distortion[i] * radius ** (2 * (i + 1))
-            denominator += self.radial_distortion[i + 3] * radius ** (2 * (i + 1))
-        f = numerator / denominator
-        xpp = point[0] * f + 2 * self.tangential_disto[0] * point[0] * point[1] + \
-            self.tangential_disto[1] * (radius ** 2 + 2 * point[0] ** 2) + \
-            self.thin_prism_disto[0] * radius ** 2 + self.thin_prism_disto[1] * radius ** 4
-        ypp = point[1] * f + 2 * self.tangential_disto[1] * point[0] * point[1] + \
-            self.tangential_disto[0] * (radius ** 2 + 2 * point[1] ** 2) + \
-            self.thin_prism_disto[2] * radius ** 2 + self.thin_prism_disto[3] * radius ** 4
-        return np.array([xpp, ypp], dtype=np.float32)          # float32, like the reference (:247)
+        return self._distort_block(np.asarray(point, dtype=np.float64)[None, :2])[0]
+
+    def project_points(self, points3D, distort=True):
+        """(N,3) world points -> (N,3) rows [x_px, y_px, 1]; a point at depth <= 1e-3 gives a row of zeros."""
+        P = np.atleast_2d(np.asarray(points3D, dtype=np.float64))
+        cam = (P - self.position) @ np.asarray(self.rotation).T
+        front = cam[:, 2] > 1e-3
+        out = np.zeros((P.shape[0], 3))
+        if front.any():
+            nrm = cam[front, :2] / cam[front, 2:3]
+            # float32 values times a float64 focal length: float64 arithmetic from here on (numpy 1.24 promotion)
+            d = self._distort_block(nrm).astype(np.float64) if distort else nrm
+            out[front, 0] = d[:, 0] * float(self.xfocal_length) + self.principal_point[0]
+            out[front, 1] = d[:, 1] * float(self.yfocal_length) + self.principal_point[1]
+            out[front, 2] = 1.0
+        return out
 
     def project_point(self, point3D, distort=True):
-        point = point3D - self.position
-        rotated_point = self.rotation @ np.transpose(point)
-        if rotated_point[2] <= 1e-3:
-            return np.zeros(3)
-        rotated_point = rotated_point / rotated_point[2]
-        d = self.distort(rotated_point) if distort else rotated_point
-        # float32 * float64 focal length -> float64, the promotion of the reference's pinned numpy 1.24
-        x = float(d[0]) * float(self.xfocal_length) + self.principal_point[0]
-        y = float(d[1]) * float(self.yfocal_length) + self.principal_point[1]
-        return np.array([x, y, 1])
+        return self.project_points(np.asarray(point3D, dtype=np.float64).reshape(1, 3), distort)[0]
 
     def projection_rmse(self, matched_points):
-        target_pts = np.array([pt[0] for pt in matched_points])
-        img_pts = np.array([pt[1] for pt in matched_points])
-        projected = np.stack([self.project_point(p3d)[:2] for p3d in target_pts], axis=0)
-        return np.mean(np.linalg.norm(img_pts - projected, ord=2.0, axis=-1))
+        """MEAN of the per-point pixel distances (the reference's definition, not a root-mean-square)."""
+        world = np.array([m[0] for m in matched_points], dtype=np.float64)
+        seen = np.array([m[1] for m in matched_points], dtype=np.float64)
+        return np.mean(np.linalg.norm(seen - self.project_points(world)[:, :2], axis=1))
 
     def scale_resolution(self, factor):
-        self.xfocal_length = self.xfocal_length * factor
-        self.yfocal_length = self.yfocal_length * factor
-        self.image_width = self.image_width * factor
-        self.image_height = self.image_height * factor
-        self.principal_point = (self.image_width / 2, self.image_height / 2)
-        self.calibration = np.array([[self.xfocal_length, 0, self.principal_point[0]],
-                                     [0, self.yfocal_length, self.principal_point[1]], [0, 0, 1]], dtype='float')
-
-    def estimate_calibration_matrix_from_plane_homography(self, homography):
-        """Image of the absolute conic from one plane homography (camera.py:366-426, HZ alg. 8.2)."""
-        H = np.reshape(homography, (9,))
-        A = np.zeros((5, 6))
-        A[0, 1] = 1.
-        A[1, 0] = 1.
-        A[1, 2] = -1.
-        A[2, 3] = self.principal_point[1] / self.principal_point[0]
-        A[2, 4] = -1.0
-        A[3] = [H[0] * H[1], H[0] * H[4] + H[1] * H[3], H[3] * H[4], H[0] * H[7] + H[1] * H[6],
-                H[3] * H[7] + H[4] * H[6], H[6] * H[7]]
-        A[4] = [H[0] * H[0] - H[1] * H[1], 2 * H[0] * H[3] - 2 * H[1] * H[4], H[3] * H[3] - H[4] * H[4],
-                2 * H[0] * H[6] - 2 * H[1] * H[7], 2 * H[3] * H[6] - 2 * H[4] * H[7], H[6] * H[6] - H[7] * H[7]]
-        _, _, vh = np.linalg.svd(A)
-        w = vh[-1]
-        W = np.array([[w[0], w[1], w[3]], [w[1], w[2], w[4]], [w[3], w[4], w[5]]]) / w[5]
-        try:
-            Ktinv = np.linalg.cholesky(W)
-        except np.linalg.LinAlgError:
-            return False, np.eye(3)
-        K = np.linalg.inv(np.transpose(Ktinv))
-        K /= K[2, 2]
-        self.xfocal_length = K[0, 0]
-        self.yfocal_length = K[1, 1]
-        self.principal_point = (self.image_width / 2, self.image_height / 2)
-        self.calibration = np.array([[self.xfocal_length, 0, self.principal_point[0]],
-                                     [0, self.yfocal_length, self.principal_point[1]], [0, 0, 1]], dtype='float')
-        return True, K
+        self.image_width, self.image_height = self.image_width * factor, self.image_height * factor
+        self._set_intrinsics(self.xfocal_length * factor, self.yfocal_length * factor,
+                             (self.image_width / 2, self.image_height / 2))

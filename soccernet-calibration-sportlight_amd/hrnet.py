@@ -9,6 +9,7 @@ into the conv weights before they are packed for the MFMA kernels.  PyTorch only
 """
 import ctypes
 import os
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 import torch
@@ -21,14 +22,41 @@ BN_EPS = 1e-5
 DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
 
-def load_config(name_or_path):
-    """yaml with the reference's field names (src/models/hrnet/model_config/*.yaml)."""
-    if isinstance(name_or_path, dict):
-        cfg = dict(name_or_path)
-    else:
+def _plain(obj):
+    """Nested mappings / sequences of any kind (dict, OmegaConf DictConfig / ListConfig -- what hydra.utils.instantiate
+    leaves in an argus checkpoint's params -- or a yaml tree) -> plain dicts and lists."""
+    try:
+        from omegaconf import OmegaConf
+        if OmegaConf.is_config(obj):
+            return OmegaConf.to_container(obj, resolve=True)
+    except ImportError:
+        pass
+    if isinstance(obj, Mapping):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)) or (isinstance(obj, Sequence) and not isinstance(obj, (str, bytes))):
+        return [_plain(v) for v in obj]
+    return obj
+
+
+def load_config(name_or_path, head=None, upscale=None):
+    """yaml with the reference's field names (src/models/hrnet/model_config/*.yaml), a mapping holding them (the
+    reference reads them by attribute from an OmegaConf node, hrnet.py:256-314) or the name of a packaged config.
+    `head` / `upscale`: values the CALLING model class fixes in code rather than in the yaml -- the line network
+    hard-codes Softmax and has no upscale branch (src/models/line/hrnet.py:86-102, 236-245), its yaml carries neither key."""
+    if isinstance(name_or_path, Mapping) or type(name_or_path).__name__ in ('DictConfig',):
+        cfg = _plain(name_or_path)
+    elif isinstance(name_or_path, (str, os.PathLike)):
         path = name_or_path if os.path.exists(str(name_or_path)) else os.path.join(_CFG_DIR, f'{name_or_path}.yaml')
+        if not os.path.exists(path):
+            raise _lib.SncalError(f'hrnet_config: no such file or packaged config: {name_or_path!r}')
         with open(path) as f:
             cfg = yaml.safe_load(f)
+    else:
+        raise _lib.SncalError(f'hrnet_config must be a mapping, a yaml path or a packaged config name, not {type(name_or_path).__name__}')
+    if head is not None:
+        cfg['head'] = head
+    if upscale is not None:
+        cfg['upscale'] = upscale
     cfg.setdefault('upscale', 1)
     cfg.setdefault('head', 'logsoftmax')
     return cfg
@@ -65,10 +93,10 @@ class HRNetHeatmap:
     """Inference-only HRNet on the HIP engine.  ``dtype``: 'bf16' (fast path) or 'fp32' (parity path)."""
 
     def __init__(self, hrnet_config, num_refinement_stages: int = 0, num_heatmaps: int = None,
-                 dtype: str = 'bf16', device='cuda:0'):
+                 dtype: str = 'bf16', device='cuda:0', head=None, upscale=None):
         if num_refinement_stages != 0:
             raise _lib.SncalError('refinement stages are never instantiated by the reference configs; unsupported')
-        self.cfg = load_config(hrnet_config)
+        self.cfg = load_config(hrnet_config, head=head, upscale=upscale)
         self.dtype = DTYPES[dtype]
         self.device = torch.device(device)
         self._L = _lib.lib()

@@ -8,23 +8,28 @@ checkpoint is the plain ``torch.save`` dict {'model_name', 'params', 'nn_state_d
 import torch
 
 from . import _lib
-from .hrnet import HRNetHeatmap
+from .hrnet import HRNetHeatmap, _plain
 from .transforms import HRNetPredictionTransform, EHMPredictionTransform
 
 
 class HRNetMetaModel:
     """Inference-side mirror of the argus Model subclasses (keypoint: HRNetMetaModel, line: EHMMetaModel)."""
     prediction_transform_cls = HRNetPredictionTransform
+    # what the model CLASS fixes in code, whatever the yaml says (None = read the yaml): the keypoint network's head and
+    # upscale come from its config (src/models/hrnet/hrnet.py:306-330)
+    head = None
+    upscale = None
 
     def __init__(self, params: dict, dtype: str = 'bf16'):
         self.params = params
         dev = params.get('device', 'cuda:0')
         self.device = torch.device(dev[0] if isinstance(dev, (list, tuple)) else dev)
-        nn_params = dict(params['nn_module'])
+        nn_params = _plain(params['nn_module'])
         self.nn_module = HRNetHeatmap(nn_params['hrnet_config'],
                                       num_refinement_stages=nn_params.get('num_refinement_stages', 0),
-                                      num_heatmaps=nn_params.get('num_heatmaps'), dtype=dtype, device=self.device)
-        pt = params.get('prediction_transform', {})
+                                      num_heatmaps=nn_params.get('num_heatmaps'), dtype=dtype, device=self.device,
+                                      head=self.head, upscale=self.upscale)
+        pt = _plain(params.get('prediction_transform', {}) or {})
         self.prediction_transform = self.prediction_transform_cls(**pt) if pt else None
 
     def predict(self, x: torch.Tensor) -> torch.Tensor:
@@ -42,7 +47,11 @@ class HRNetMetaModel:
 
 
 class EHMMetaModel(HRNetMetaModel):
+    """Line model.  Its network ends in a hard-coded Softmax and never upscales (src/models/line/hrnet.py:86-102,
+    236-245); the yaml inside a genuine checkpoint (line/model_config/hrnet_w48.yaml) has no 'head' / 'upscale' key."""
     prediction_transform_cls = EHMPredictionTransform
+    head = 'softmax'
+    upscale = 1
 
 
 _MODELS = {'HRNetMetaModel': HRNetMetaModel, 'EHMMetaModel': EHMMetaModel}
@@ -50,8 +59,12 @@ _MODELS = {'HRNetMetaModel': HRNetMetaModel, 'EHMMetaModel': EHMMetaModel}
 
 def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str = 'bf16', **_ignored):
     """argus.load_model(path, loss=None, optimizer=None, device=...) for the two inference models."""
-    state = torch.load(file_path, map_location='cpu', weights_only=False)
-    params = dict(state['params'])
+    try:
+        state = torch.load(file_path, map_location='cpu', weights_only=False)
+    except ModuleNotFoundError as e:       # checkpoints written under hydra pickle OmegaConf nodes inside params
+        raise _lib.SncalError(f'{file_path}: unpickling the checkpoint needs the module {e.name!r} (argus checkpoints of the '
+                              'reference hold OmegaConf nodes in params: `pip install omegaconf`)') from e
+    params = dict(_plain(state['params']))
     params['device'] = device
     cls = _MODELS.get(state.get('model_name', 'HRNetMetaModel'), HRNetMetaModel)
     model = cls(params, dtype=dtype)

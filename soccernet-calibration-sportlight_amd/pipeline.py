@@ -40,18 +40,24 @@ class CalibrationPipeline:
         convolutions on the main stream never wait for it."""
         main = torch.cuda.current_stream(self.device)
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
-        ready = torch.cuda.Event()
-        ready.record(main)
         if self.line_net is not None:
             from .lines import lines_to_points_device
             from .transforms import EHMPredictionTransform
             heat_l, _ = self.line_net.forward(frames, want_heat=True)
             peaks = EHMPredictionTransform.mask_heat_points_gauss(heat_l, sigma=self.line_sigma)
             d_lp = lines_to_points_device(peaks, scale=self.line_scale, prob_thre=self.line_prob_thre)
-            ready.record(main)           # the solve also waits for the line branch
         else:
             lp = self.calibrator.line_points_array(names)
-            d_lp = torch.from_numpy(lp).to(self.device, non_blocking=True) if lp is not None else None
+            d_lp = None
+            if lp is not None:              # pinned staging buffer: the upload is a real asynchronous copy on `main`
+                d_lp = torch.from_numpy(lp).pin_memory().to(self.device, non_blocking=True)
+        # everything the solve reads (keypoints, line points) is produced on `main` ABOVE this record
+        ready = torch.cuda.Event()
+        ready.record(main)
+        extra_ready = None
+        if extra_keypoints is not None:     # produced by the caller, on whatever stream is current for them: order it too
+            extra_ready = torch.cuda.Event()
+            extra_ready.record(main)
         with torch.cuda.stream(self.solve_stream):
             self.solve_stream.wait_event(ready)
             kpts.record_stream(self.solve_stream)
@@ -60,6 +66,8 @@ class CalibrationPipeline:
             rec = self.calibrator.solve_device(kpts, d_lp)
             out = [kpts, rec]
             if extra_keypoints is not None:
+                self.solve_stream.wait_event(extra_ready)
+                extra_keypoints.record_stream(self.solve_stream)
                 out.append(self.calibrator.solve_device(extra_keypoints))
             if gather:
                 from .dist import pack_records, gather_records

@@ -91,7 +91,9 @@ class CameraCreator:
         c = _lib.VoterCfg()
         c.algorithm = ALGORITHMS[self.algorithm_name]
         c.conf_thresh = float(self.conf_thresh)
-        ths = list(self.conf_threshs)[:4]
+        ths = list(self.conf_threshs)
+        if len(ths) > 4:       # sncal_voter_cfg carries four thresholds; the reference loops over any number (prediction.py:245-257)
+            raise _lib.SncalError(f'conf_threshs holds {len(ths)} thresholds; sncal_voter_cfg carries at most 4')
         c.n_conf_threshs = len(ths)
         for i, t in enumerate(ths):
             c.conf_threshs[i] = float(t)

@@ -217,3 +217,40 @@ def test_jpeg_host_parser_survives_damaged_streams():
         assert (buf[cap:] == 0x5A5A).all()
         seen.add(st2)
     assert {0, -1} <= seen
+
+
+def test_config_mappings_that_are_not_dicts():
+    """Checkpoints written under hydra hold OmegaConf nodes: Mappings / Sequences that are not dict / list.  load_config
+    and the meta-model constructor must take them; class-level head/upscale override whatever the yaml says."""
+    import collections.abc
+    import pytest
+    import sncal_amd
+    from sncal_amd import hrnet as H
+
+    class Node(collections.abc.Mapping):
+        def __init__(self, d): self._d = d
+        def __getitem__(self, k):
+            v = self._d[k]
+            return Node(v) if isinstance(v, dict) else Seq(v) if isinstance(v, list) else v
+        def __iter__(self): return iter(self._d)
+        def __len__(self): return len(self._d)
+
+    class Seq(collections.abc.Sequence):
+        def __init__(self, v): self._v = v
+        def __getitem__(self, i): return self._v[i]
+        def __len__(self): return len(self._v)
+
+    base = H.load_config('line_hrnet_w48')
+    bare = {k: v for k, v in base.items() if k not in ('head', 'upscale')}
+    cfg = H.load_config(Node(bare), head='softmax', upscale=1)
+    assert type(cfg) is dict and type(cfg['stage2']) is dict and type(cfg['stage2']['num_channels']) is list
+    assert cfg['head'] == 'softmax' and cfg['upscale'] == 1 and cfg['stage4']['num_channels'] == [48, 96, 192, 384]
+    assert H.load_config(Node(bare))['head'] == 'logsoftmax'           # the keypoint class reads the yaml / default
+    d = H._desc(cfg)
+    assert d.head_softmax == 1 and d.upscale == 1 and d.num_classes == 23
+    with pytest.raises(sncal_amd._lib.SncalError):
+        H.load_config(12345)
+    with pytest.raises(sncal_amd._lib.SncalError):
+        H.load_config('no_such_config_name')
+    with pytest.raises(sncal_amd._lib.SncalError):                       # ADVICE r1: more thresholds than the C struct carries
+        sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_threshs=[0.5, 0.4, 0.3, 0.2, 0.1])._cfg()

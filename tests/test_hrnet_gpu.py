@@ -208,3 +208,32 @@ def test_frames_are_independent_of_batch_size_and_position(sncal, cuda):
     h3, _ = net.forward(x[:3].contiguous(), want_heat=True)
     h2, _ = net.forward(x[:2].contiguous(), want_heat=True)
     assert torch.equal(h3[:2], h2)
+
+
+def test_load_model_ehm_checkpoint_without_head_key(sncal, cuda, tmp_path, gold_dir):
+    """A genuine EHMMetaModel checkpoint: params.nn_module.hrnet_config is the line yaml, which has NO 'head' and NO
+    'upscale' key (src/models/line/model_config/hrnet_w48.yaml) -- the Softmax head is hard-coded in the model class
+    (src/models/line/hrnet.py:101).  load_model must build the softmax / stride-4 network from the class, not from the
+    yaml; checked against the reference-captured line golden and through predict()'s two-peak decode."""
+    g = np.load(os.path.join(gold_dir, 'line_w18_64x96.npz'))
+    cfg = hr.load_config('line_hrnet_w18')
+    bare = {k: v for k, v in cfg.items() if k not in ('head', 'upscale')}
+    sd = hr.seeded_state_dict(cfg, int(g['seed']), float(g['head_gain']))
+    x = hr.seeded_input(int(g['batch']), int(g['hw'][0]), int(g['hw'][1]), int(g['seed']) + 1)
+    ck = {'model_name': 'EHMMetaModel',
+          'params': {'nn_module': {'hrnet_config': bare, 'num_refinement_stages': 0, 'num_heatmaps': 23},
+                     'prediction_transform': {'scale': 4, 'sigma': 6}, 'device': 'cuda:0'},
+          'nn_state_dict': sd}
+    path = str(tmp_path / 'line.pth')
+    torch.save(ck, path)
+    model = sncal.load_model(path, loss=None, optimizer=None, device='cuda:0', dtype='fp32')
+    assert type(model).__name__ == 'EHMMetaModel'
+    assert model.nn_module.cfg['head'] == 'softmax' and model.nn_module.cfg['upscale'] == 1
+    heat = model.nn_module(x.to(cuda))[-1]
+    assert np.abs(heat.cpu().numpy() - g['out']).max() <= 2e-5
+    s = heat.sum(dim=1)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)           # a softmax head, not log-softmax
+    pred = model.predict(x)
+    assert pred.shape == (x.shape[0], 23, 2, 3)
+    assert np.array_equal(pred.cpu().numpy()[..., :2], od.line_decode(g['out'], 6.0, 4.0)[..., :2])
+    assert float(pred[..., 2].max()) > 0.0                            # the bug this pins returned p = 0 everywhere

@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the per-frame calibration hot path on MI355X (metric of BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4] [--dtype bf16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 
-One step = one pass of the hot path over one batch of frames already resident in HBM (BASELINE config C3:
-HRNet-W48, 960x540, batch 64 per GPU): NCHW->NHWC, all convolutions / fuse / head kernels, log-softmax,
-keypoint decode, and the batched camera solve (CameraCreator 'iterative_voter' with the make_submit.py
-parameters).  The solve runs twice per step: on the keypoints decoded from the network output (real data
-dependency; random-init weights give few confident points) and on a resident batch of synthetic
-projected-template keypoints (the realistic solve workload).  With N > 1 every rank processes
-its own 64 frames (weak scaling, frames are independent) and one RCCL all_gather of the per-frame records
-closes the step.  Rank 0 prints ONE JSON line.
+One step = one pass of the hot path over one batch of frames already resident in HBM (BASELINE config C3: HRNet-W48,
+960x540, batch 64 per GPU): NCHW->NHWC, all convolutions / fuse / head kernels, log-softmax + keypoint decode, and the
+batched camera solve (CameraCreator 'iterative_voter' with the make_submit.py parameters) ON THE KEYPOINTS THE NETWORK
+DECODED -- the data dependency of the real path.  --workload c4 adds the line network (HRNet-W48 stride 4), its two-peak
+decode and the on-device line join in front of the same solve (BASELINE config C4).
+
+Data.  No trained checkpoint ships with the reference and random-init weights give flat heatmaps whose argmax cannot
+drive the solve.  The workload therefore keeps the random-init W48 network and installs one designed signal path
+(sncal_amd.synth.peaked_state_dict / stamped_frames): frames carry per-keypoint code stamps at the projections of the
+pitch template through sampled broadcast cameras, the matched stem filters feed the head, and the heatmaps come out
+peaked (p ~ 0.99) on known cells for the visible keypoints on top of the random network's noise -- what a trained
+network hands to HRNetPredictionTransform / CameraCreator.  Every convolution runs at its full size on dense data.
+
+Parity of the benchmarked path rides on the same line (`parity`, computed OUTSIDE the timed region on the same frames):
+the benchmarked engine against this build's exact-fp32 engine (the one pinned to the reference goldens by
+tests/test_hrnet_gpu.py): keypoint-index agreement, and the relative difference of the solved cameras' reprojection
+error; plus the fp32 engine's own frames/s.  With N > 1 every rank processes its own 64 frames (weak scaling, frames
+are independent) and one RCCL all_gather of the per-frame records closes the step.  Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -33,14 +42,19 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_FRAME = 2 * 253910384640          # conv MACs of the reference's direct formulation x2
+# conv MACs of the reference's direct formulation x2
+FLOP_KEYPOINT_NET = 2 * 253910384640
+FLOP_LINE_NET = 2 * 185690000000
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 BATCH = 64
+SOLVER_KW = dict(conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter', lines_file=None,
+                 max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0, min_points_per_plane=6,
+                 min_points_for_refinement=6, reliable_thresh=57)          # make_submit.py:45-50
 
 
 def seeded_weights(cfg, seed):
-    """Random-init weights of the W48 architecture (no checkpoints ship with the reference).  Same recipe as
-    the test-suite generator, restated here so that the timed path never imports oracle/."""
+    """Random-init weights of the architecture (no checkpoints ship with the reference).  Same recipe as the
+    test-suite generator, restated here so that the timed path never imports oracle/."""
     import sncal_amd
     rng = np.random.Generator(np.random.PCG64(seed))
     net = sncal_amd.HRNetHeatmap(cfg, dtype='bf16', device='cpu')
@@ -63,34 +77,105 @@ def seeded_weights(cfg, seed):
     return sd
 
 
-def cpu_baseline(sd, cfg_name, n_frames=2, n_solve=6):
-    """The oracle (CPU restatement of the reference's algorithm) timed on this host's cores: torch-CPU fp32
-    HRNet forward + numpy decode on `n_frames` frames, numpy solve on `n_solve` synthetic frames."""
+# ---- CPU baseline: the oracle on this host's cores, bounded sample --------------------------------
+def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0):
+    """torch-CPU fp32 forward at batch 8 on all physical cores (warm-up 2, median of up to 5 runs inside the budget),
+    numpy decode, numpy camera solve single-process and on an all-cores process pool (the reference uses 16 workers,
+    make_submit.py:25).  `frames` (>=8,3,540,960) CPU tensor, `kpts` decoded keypoints (n,57,3) to solve."""
     from oracle import decode as od
     from oracle import hrnet_ref as hr
-    from oracle import solve as osolve
-    import sncal_amd
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except ImportError:
+        cores = os.cpu_count()
+    cores = int(cores)
     cfg = hr.load_config(cfg_name)
-    cores = torch.get_num_threads()
-    x = torch.rand((1, 3, 540, 960))
-    hr.forward(sd, x, cfg)                                    # warm-up (oneDNN primitive creation)
-    t0 = time.time()
-    for _ in range(n_frames):
-        logp = hr.forward(sd, x, cfg)
-    t_net = (time.time() - t0) / n_frames
-    t0 = time.time()
-    od.keypoint_decode(logp.numpy(), (540, 960))
-    t_dec = time.time() - t0
-    kps = sncal_amd.synth.synthetic_keypoints(n_solve, seed=123)
-    oc = osolve.CameraCreatorOracle()
-    t0 = time.time()
-    for k in kps:
-        oc(k, None)
-    t_solve = (time.time() - t0) / n_solve
-    return {'value': round(1.0 / (t_net + t_dec + t_solve), 4), 'unit': 'frames/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{n_frames} frames HRNet-W48 960x540 fp32 torch-CPU forward ({t_net:.2f} s/frame) + numpy decode '
-                      f'({t_dec * 1e3:.0f} ms/frame) + {n_solve} frames numpy camera solve ({t_solve * 1e3:.0f} ms/frame), '
-                      'single process, stages serial'}
+    torch.set_num_threads(cores)
+    x = frames[:8].contiguous()
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(2):                                           # warm-up (oneDNN primitive creation, thread pool)
+            logp = hr.forward(sd, x, cfg)
+        runs = []
+        while len(runs) < 5 and (len(runs) < 3 or time.perf_counter() - t_start < budget_s):
+            t0 = time.perf_counter()
+            logp = hr.forward(sd, x, cfg)
+            runs.append(time.perf_counter() - t0)
+    t_net = float(np.median(runs)) / x.shape[0]
+    lp = logp.numpy()
+    t0 = time.perf_counter()
+    od.keypoint_decode(lp, (540, 960))
+    t_dec = (time.perf_counter() - t0) / x.shape[0]
+    # camera solve: N independent worker processes (plain scripts: they never import torch or touch the GPU runtime), every
+    # worker solves `per` frames after one untimed call; pool rate = frames / slowest worker's solve time
+    import subprocess
+    import tempfile
+    kp = np.asarray(kpts, dtype=np.float32)
+    worker = os.path.join(ROOT, 'oracle', 'solve_worker.py')
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'kpts.npy')
+        np.save(path, kp)
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+
+        def run_pool(n, per):
+            procs = [subprocess.Popen([sys.executable, worker, path, str(i * per), str(per)], stdout=subprocess.PIPE, env=env)
+                     for i in range(n)]
+            outs = [p.communicate()[0].decode().split() for p in procs]
+            return [float(o[0]) for o in outs], sum(int(o[1]) for o in outs)
+        t1, _ = run_pool(1, 4)
+        t_solve1 = t1[0] / 4
+        workers = max(1, min(cores, 64))
+        per = 3
+        try:
+            tw, found = run_pool(workers, per)
+            fps_pool = workers * per / max(tw)
+            pool_txt = f'{workers}-process pool {fps_pool:.0f} frames/s ({found}/{workers * per} cameras)'
+        except Exception as e:                                       # a host that cannot start the workers: single-process figure
+            fps_pool = 1.0 / t_solve1
+            pool_txt = f'pool unavailable ({type(e).__name__})'
+    stages = {'forward': 1.0 / t_net, 'decode': 1.0 / t_dec, 'solve': fps_pool}
+    return {'value': round(min(stages.values()), 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle (CPU restatement) on {cores} physical cores: HRNet-W48 960x540 fp32 torch-CPU forward, batch 8, '
+                      f'warm-up 2 + median of {len(runs)} runs = {t_net:.3f} s/frame ({1 / t_net:.2f} frames/s); numpy decode '
+                      f'{t_dec * 1e3:.0f} ms/frame; numpy camera solve on the decoded keypoints {t_solve1 * 1e3:.0f} ms/frame single '
+                      f'process, {pool_txt}; value = slowest stage of the pipelined three (BASELINE.md 4.5)',
+            'stages_fps': {k: round(v, 3) for k, v in stages.items()},
+            'serial_fps': round(1.0 / (t_net + t_dec + 1.0 / fps_pool), 4)}
+
+
+def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3):
+    """The benchmarked engine vs this build's exact-fp32 engine on the SAME frames (outside the timed region)."""
+    net32 = sncal_amd.HRNetHeatmap(cfg_name, dtype='fp32', device=dev)
+    net32.load_state_dict(sd)
+    pipe = sncal_amd.CalibrationPipeline(net32, cc, decode_size=(540, 960))
+    out = pipe.submit(x)
+    pipe.join()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = pipe.submit(x)
+    pipe.join()
+    torch.cuda.synchronize()
+    fps32 = steps * x.shape[0] / (time.perf_counter() - t0)
+    kp32 = out[0].cpu().numpy()
+    kpf = kp_fast.cpu().numpy()
+    same = (kp32[..., :2] == kpf[..., :2]).all(-1)                       # (B,57) identical (x, y) indices
+    usable = kp32[..., 2] >= 0.2                                         # rows any of the solver's thresholds can take
+    # both keypoint sets through the same solve call (no line points), so the comparison is like for like in every workload
+    r32, rf = cc.records(out[1]), cc.records(cc.solve_device(kp_fast))
+    both = [i for i in range(len(r32)) if r32[i].status != 0 and rf[i].status != 0]
+    deltas = [abs(rf[i].rmse - r32[i].rmse) / r32[i].rmse for i in both if r32[i].rmse > 0]
+    return {'vs': 'exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py)',
+            'frames': int(x.shape[0]),
+            'index_agreement': round(float(same[usable].mean()) if usable.any() else 1.0, 6),
+            'usable_keypoints': int(usable.sum()),
+            'index_agreement_all_rows': round(float(same.mean()), 6),
+            'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
+            'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_benchmarked': sum(r.status != 0 for r in rf),
+            'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
+            'solve_parity': 'vs the build\'s own oracle only: OpenCV parity unpinned (cv2 not installable offline)',
+            'fp32_engine_frames_per_s': round(fps32, 1)}
 
 
 def main():
@@ -99,12 +184,16 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c4'],
+                    help='c3: HRNet-W48 keypoint net + decode + solve (the metric\'s configuration); c4: + the W48 line net, '
+                         'its two-peak decode and the device line join in front of the solve')
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--lanes', type=int, default=1,
                     help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md 5: '
-                         '2 lanes fill kernel tails and launch gaps, +7 %% frames/s, but per-kernel HIP-event durations then '
-                         'measure a shared GPU, so the roofline object is only meaningful at 1)')
+                         '2 lanes fill kernel tails and launch gaps, but per-kernel HIP-event durations then measure a shared GPU, '
+                         'so the roofline object is only meaningful at 1)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -125,48 +214,51 @@ def main():
 
     import sncal_amd
     cfg_name = 'hrnet_w48'
-    sd = seeded_weights(cfg_name, seed=1)
+    sd = sncal_amd.synth.peaked_state_dict(seeded_weights(cfg_name, seed=1))
     B = args.batch
     L = max(1, args.lanes)
     if B % L:
         raise SystemExit(f'--batch {B} is not a multiple of --lanes {L}')
-    nets = []
+    c4 = args.workload == 'c4'
+    sd_line = seeded_weights('line_hrnet_w48', seed=2) if c4 else None
+    nets, lnets = [], []
     for _ in range(L):
         net = sncal_amd.HRNetHeatmap(cfg_name, dtype=args.dtype, device=dev)
         net.load_state_dict(sd)
         nets.append(net)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    x = torch.rand((B, 3, 540, 960), device=dev, generator=gen)          # synthetic frames, resident in HBM
-    kp_synth = torch.from_numpy(sncal_amd.synth.synthetic_keypoints(B, seed=77 + rank)).to(dev)
-    cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2],
-                                 algorithm='iterative_voter', lines_file=None, max_rmse=55.0, max_rmse_rel=5.0,
-                                 min_points=5, min_focal_length=10.0, min_points_per_plane=6,
-                                 min_points_for_refinement=6, reliable_thresh=57)
-    pipes = [sncal_amd.CalibrationPipeline(n, cc, decode_size=(540, 960)) for n in nets]
+        if c4:
+            ln = sncal_amd.HRNetHeatmap('line_hrnet_w48', dtype=args.dtype, device=dev)
+            ln.load_state_dict(sd_line)
+            lnets.append(ln)
+    frames_cpu, expect = sncal_amd.synth.stamped_frames(B, seed=1000 + rank)     # synthetic frames, then resident in HBM
+    frames_cpu = torch.from_numpy(frames_cpu)
+    x = frames_cpu.to(dev)
+    cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **SOLVER_KW)
+    pipes = [sncal_amd.CalibrationPipeline(nets[i], cc, decode_size=(540, 960), line_net=lnets[i] if c4 else None)
+             for i in range(L)]
     lane_streams = [None] if L == 1 else [torch.cuda.Stream(device=dev) for _ in range(L)]
     bl = B // L
     xs = [x[i * bl:(i + 1) * bl] for i in range(L)]
-    kps = [kp_synth[i * bl:(i + 1) * bl].contiguous() for i in range(L)]
     last = {}
-    diag_nosolve = os.environ.get('SNCAL_BENCH_DIAG') == 'nosolve'
-    diag_noprof = os.environ.get('SNCAL_BENCH_DIAG') == 'noprof'
+    diag = os.environ.get('SNCAL_BENCH_DIAG')
+    diag_nosolve = diag == 'nosolve'
+    diag_noprof = diag == 'noprof'
 
     def step():
-        # forward + decode on the main stream; both solves on the pipeline's side stream (they overlap the next
-        # step's convolutions); every solve is complete before the closing fence of the timed region
-        # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on
-        # the side stream behind the solves
+        # forward + decode on the main stream; the solve of THESE keypoints on the pipeline's side stream (it overlaps the
+        # next step's convolutions); every solve is complete before the closing fence of the timed region.
+        # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on the
+        # side stream behind the solve
         for i in range(L):
             if diag_nosolve:                             # diagnosis only: network + decode, no solves (not a valid bench line)
                 nets[i].forward(xs[i], want_heat=False, decode_size=(540, 960))
                 continue
             if lane_streams[i] is None:
-                out = pipes[i].submit(xs[i], extra_keypoints=kps[i], gather=use_dist)
+                out = pipes[i].submit(xs[i], gather=use_dist)
             else:
                 with torch.cuda.stream(lane_streams[i]):
-                    out = pipes[i].submit(xs[i], extra_keypoints=kps[i], gather=use_dist)
-            last[i] = out[2]
+                    out = pipes[i].submit(xs[i], gather=use_dist)
+            last[i] = out
 
     def fence():
         for i in range(L):
@@ -197,8 +289,6 @@ def main():
                 m[k] += q[k]
     for n in nets:
         n.set_profiling(0 if diag_noprof else 2)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    solve_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -212,15 +302,18 @@ def main():
                 m[k] += q[k]
         n.set_profiling(False)
     prof = list(merged.values())
-    if os.environ.get('SNCAL_BENCH_DIAG'):               # diagnosis runs print the step time only
-        print('diag', os.environ['SNCAL_BENCH_DIAG'], round(dt / args.steps * 1e3, 3), 'ms/step')
+    if diag:                                             # diagnosis runs print the step time only
+        print('diag', diag, round(dt / args.steps * 1e3, 3), 'ms/step')
         return
-    # solve-stage time, measured separately after the timed region (torch events see torch's current stream,
-    # which is the stream libsncal launches on)
-    rec_syn = cc.solve_device(kp_synth)
+    # solve-stage time on the decoded keypoints, measured separately after the timed region (torch events see torch's
+    # current stream, which is the stream libsncal launches on)
+    kp_fast = torch.cat([last[i][0] for i in range(L)], dim=0)
+    rec_fast = torch.cat([last[i][1] for i in range(L)], dim=0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    rec_tmp = cc.solve_device(kp_fast)
     ev[0].record()
     for _ in range(3):
-        cc.solve_device(kp_synth, out=rec_syn)
+        cc.solve_device(kp_fast, out=rec_tmp)
     ev[1].record()
     torch.cuda.synchronize()
     solve_ms = ev[0].elapsed_time(ev[1]) / 3
@@ -229,7 +322,12 @@ def main():
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    n_cam = sum(1 for r in cc.records(rec_syn) if r.status != 0)
+    recs = cc.records(rec_fast)
+    n_cam = sum(1 for r in recs if r.status != 0)
+    kpf = kp_fast.cpu().numpy()
+    vis = expect[..., 2] > 0
+    hit = float((kpf[..., :2] == expect[..., :2]).all(-1)[vis].mean())
+    conf_vis = kpf[..., 2][vis]
 
     if rank == 0:
         assert len(prof) == 1, [p['kernel'] for p in prof]      # focus mode: the dominant variant only
@@ -238,23 +336,28 @@ def main():
         total_ms = sum(p['ms'] for p in warm)
         warm_dom = next(p for p in warm if p['kernel'] == dom['kernel'])
         ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/r01_pmc_hbm_traffic.md)
+        traffic = None      # HBM bytes per launch from a separate rocprofv3 --pmc pass (tools/pmc_pass.sh -> profiles/pmc_traffic.json)
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
                 traffic = json.load(f).get(dom['kernel'])
         except OSError:
             pass
         peak = PEAK_TFLOPS[args.dtype]
+        flop_frame = FLOP_KEYPOINT_NET + (FLOP_LINE_NET if c4 else 0)
+        wl = ('C4: HRNet-W48 keypoint net + HRNet-W48 line net, 960x540, batch 64 per GPU, decodes + device line join + batched camera solve (iterative_voter)'
+              if c4 else 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter) on the decoded keypoints')
         out = {
             'metric': 'frames/sec (HRNet-W48 960x540 + PnP)', 'value': round(world * B * args.steps / dt, 2),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype,
-            'data': 'synthetic (uniform-noise frames, random-init HRNet-W48; solve also driven by projected-template keypoints)',
-            'config': {'workload': 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter)',
-                       'frames_per_gpu': B, 'lanes': L, 'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
+            'data': 'synthetic (noise frames stamped with per-keypoint codes at the pitch template\'s projections through sampled cameras; '
+                    'random-init HRNet-W48 plus one matched-filter signal path -> peaked heatmaps; see bench.py docstring)',
+            'config': {'workload': wl, 'frames_per_gpu': B, 'lanes': L,
+                       'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
                        'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}',
-                       'network_tflops_reference_formulation': round(world * B * args.steps / dt * FLOP_PER_FRAME / 1e12, 1),
+                       'decoded_on_stamped_cell': round(hit, 4), 'visible_keypoint_conf_median': round(float(np.median(conf_vis)), 4),
+                       'network_tflops_reference_formulation': round(world * B * args.steps / dt * flop_frame / 1e12, 1),
                        'kernel_time_share_last_warmup_step': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(warm, key=lambda q: -q['ms'])[:8]}},
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(ach / peak, 4), 'traffic': traffic, 'launches': dom['launches'],
@@ -262,8 +365,12 @@ def main():
                          'flops_per_launch': round(dom['flops'] / dom['launches'], 0),
                          'share_of_gpu_time': round(warm_dom['ms'] / total_ms, 4)},
         }
+        if world == 1 and not args.no_parity:
+            for n in nets[1:] + lnets:
+                n._ws = None
+            out['parity'] = parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, cfg_name)
+            out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

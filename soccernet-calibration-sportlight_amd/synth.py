@@ -55,3 +55,97 @@ def synthetic_keypoints(n: int, seed: int = 0, min_visible: int = 8) -> np.ndarr
                 break
         out[b] = kp
     return out
+
+
+# ---- peaked-heatmap workload ------------------------------------------------------------------------------------
+# Random-init weights give flat, noise-like heatmaps: their argmax says nothing about a trained network and the decoded
+# keypoints cannot drive the camera solve.  The construction below keeps the whole random network (so every kernel runs
+# on realistic activations and reduced-precision error accumulates through all ~300 layers) and adds ONE designed signal
+# path through layers the reference network really has:
+#   * each keypoint class k owns a balanced +-1 code over a 2x2x3 input cell; frames carry, around the projected
+#     position of keypoint k, cells  0.5 + 0.5 * env * code_k  with a Gaussian envelope (sigma in heatmap cells);
+#   * stem filter k (model.conv1, taps of one stride-2 cell only) is the matched filter of code k, bn1 + ReLU cut it at
+#     half the matched response, so stem channel k = relu(2 env - 1) near keypoint k and 0 elsewhere (other codes
+#     correlate at <= 1/3, and the uniform-noise background (half contrast) stays 6 sigma below the cut);
+#   * the head passes stem channel k -> hidden k -> logit k with gain `peak_logit` (the stem features ARE an input of
+#     last_layer.0 in the reference: hrnet.py:489-509), every other weight stays random and adds class- and
+#     pixel-dependent noise scaled by `noise_gain`; the background class sits at peak_logit / 2.
+# Result: heatmaps peaked (p ~ 0.99) on known cells for visible keypoints, background-dominated (p ~ e^-6) for the
+# others, riding on the random network's noise -- what HRNetPredictionTransform and CameraCreator see from a trained net.
+
+def stamp_codes() -> np.ndarray:
+    """(57,3,2,2) float32 +-1: the first 57 balanced codes of length 12 with pairwise Hamming distance >= 4, in
+    lexicographic order of their +1 positions (pairwise correlation <= 1/3)."""
+    import itertools
+    codes = []
+    for pos in itertools.combinations(range(12), 6):
+        v = -np.ones(12, dtype=np.int64)
+        v[list(pos)] = 1
+        if all(int((v != c).sum()) >= 4 for c in codes):
+            codes.append(v)
+            if len(codes) == 57:
+                break
+    return np.stack(codes).reshape(57, 3, 2, 2).astype(np.float32)
+
+
+def peaked_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.25) -> dict:
+    """Copy of the random-init HRNet state dict `sd` (keypoint net, 58 classes, stem 64) with the signal path installed."""
+    import torch
+    out = {k: v.clone() for k, v in sd.items()}
+    codes = torch.from_numpy(stamp_codes())
+    w = out['model.conv1.weight']                       # (64,3,3,3), stride 2, pad 1: taps 1..2 see cell (2i..2i+1, 2j..2j+1)
+    w[:57] = 0.0
+    w[:57, :, 1:, 1:] = codes
+    for key, val in (('weight', 1.0 / 3.0), ('bias', 0.0), ('running_mean', 3.0), ('running_var', 1.0 - 1e-5)):
+        out[f'model.bn1.{key}'][:57] = val              # (resp - 3) / 3: matched response 6 -> 1, cut at half
+    w0 = out['model.last_layer.0.weight']               # (784,784,1,1); concat order: stem channels first
+    w0[:57] = 0.0
+    w0[torch.arange(57), torch.arange(57), 0, 0] = 1.0
+    out['model.last_layer.0.bias'][:57] = 0.0
+    for key, val in (('weight', 1.0), ('bias', 0.0), ('running_mean', 0.0), ('running_var', 1.0 - 1e-5)):
+        out[f'model.last_layer.1.{key}'][:57] = val
+    w1 = out['model.last_layer.3.weight']               # (58,784,1,1)
+    w1 *= noise_gain
+    w1[:, :57] = 0.0
+    w1[torch.arange(57), torch.arange(57), 0, 0] = peak_logit
+    b1 = out['model.last_layer.3.bias']
+    b1 *= noise_gain
+    b1[57] += peak_logit / 2.0
+    return out
+
+
+def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: float = 1.0, min_visible: int = 8,
+                   size=(540, 960)):
+    """(frames (n,3,H,W) float32 in [0,1] -- uniform-noise background in [0.25, 0.75) with the keypoint stamps --, expect (n,57,3) float32
+    rows [x_px, y_px, visible] on the 2-px decode grid).  Cameras are re-drawn until `min_visible` keypoints show."""
+    H, W = size
+    rng = np.random.Generator(np.random.PCG64(seed))
+    codes = stamp_codes()                                # (57,3,2,2)
+    frames = 0.25 + 0.5 * rng.random((n, 3, H, W), dtype=np.float32)      # matched-filter response of the background: sigma 0.5, the cut sits at 6 sigma
+    expect = np.zeros((n, 57, 3), dtype=np.float32)
+    hc, wc = H // 2, W // 2
+    R = int(np.ceil(2.4 * sigma_cells))                  # env < 1/2 beyond 1.18 sigma; a little margin
+    dy, dx = np.mgrid[-R:R + 1, -R:R + 1]
+    env0 = np.exp(-(dy * dy + dx * dx) / (2.0 * sigma_cells ** 2)).astype(np.float32)
+    for b in range(n):
+        while True:
+            cam = random_camera(rng)
+            q = cam.project_points(PITCH_ARRAY)
+            vis = (q[:, 2] != 0) & (q[:, 0] >= 0) & (q[:, 0] < W) & (q[:, 1] >= 0) & (q[:, 1] < H)
+            if vis.sum() >= min_visible:
+                break
+        owner_env = np.zeros((hc, wc), dtype=np.float32)
+        cells = frames[b].reshape(3, hc, 2, wc, 2)       # view: [c, i, ky, j, kx]
+        for k in np.nonzero(vis)[0]:
+            p = q[k, :2] + rng.normal(0, jitter_px, 2)
+            cj = int(min(max(round(p[0] / 2.0), 0), wc - 1))
+            ci = int(min(max(round(p[1] / 2.0), 0), hc - 1))
+            i0, i1, j0, j1 = max(ci - R, 0), min(ci + R, hc - 1), max(cj - R, 0), min(cj + R, wc - 1)
+            env = env0[i0 - ci + R:i1 - ci + R + 1, j0 - cj + R:j1 - cj + R + 1]
+            take = env > owner_env[i0:i1 + 1, j0:j1 + 1]                  # overlapping blobs: the stronger envelope owns the cell
+            owner_env[i0:i1 + 1, j0:j1 + 1] = np.where(take, env, owner_env[i0:i1 + 1, j0:j1 + 1])
+            stamp = 0.5 + 0.5 * env[None, :, None, :, None] * codes[k][:, None, :, None, :]     # (3,ni,2,nj,2)
+            blk = cells[:, i0:i1 + 1, :, j0:j1 + 1, :]
+            blk[...] = np.where(take[None, :, None, :, None], stamp, blk)
+            expect[b, k] = (2.0 * cj, 2.0 * ci, 1.0)
+    return frames, expect

@@ -1,0 +1,43 @@
+// Two-team persistent 3x3 convolution (conv_tt.hip): parameters, work items, launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sncal {
+
+constexpr int TT_MAX_MEMBERS = 3;
+constexpr int TT_TH = 8;            // output rows per tile (rows of the STACKED image, see conv_tt.hip)
+constexpr int TT_TW = 32;           // output columns per tile (two 16-pixel MFMA fragments)
+constexpr int TT_COUT = 96;         // output channels per work item (MI = 6 fragments)
+constexpr int TT_CIN = 32;          // input channels per stage (G = 4 k-groups of 8 bf16)
+
+struct TTMember {                   // one convolution of the launch: 3x3, stride 1, pad 1, bf16 NHWC, folded BN (+res)(+ReLU)
+    const void* in;                 // [N][H][W][Cin]
+    void* out;                      // [N][H][W][out_cstride], channels at out_coff
+    const void* res;                // optional residual, indexed like out
+    const void* w;                  // packed weights of the generic conv kernel for (MI = 6, G = 4): [nblk][chunk][9][6][64] x 16 B
+    const float* bias;              // folded-BN shift, padded to nblk * 96
+    int N, H, W, Cin, chunks;       // chunks = Cin / 32
+    int cout, out_cstride, out_coff, relu;
+    unsigned w_bytes, in_bytes;     // buffer-descriptor ranges
+    unsigned hp1_magic;             // floor(2^32 / (H + 1)) + 1
+};
+
+struct TTItem {                     // one output tile x one 96-channel block
+    uint16_t member, nb;
+    int32_t row0;                   // first STACKED output row of the tile (frame f, row y  ->  f * (H + 1) + y)
+    int32_t col0;
+    int32_t pad_;
+};
+
+struct TTParams {
+    TTMember m[TT_MAX_MEMBERS];
+    const TTItem* items;            // grouped by team
+    const uint32_t* team_first;     // [2 * n_wgs + 1] offsets into items
+    const uint32_t* team_stages;    // [2 * n_wgs] sum of chunks over the team's items
+    unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null
+};
+
+void launch_conv_tt(const TTParams& p, int n_wgs, hipStream_t s);
+
+}  // namespace sncal

@@ -18,6 +18,7 @@
 #include "ops.hpp"
 #include "head.hpp"
 #include "bblock.hpp"
+#include "conv_tt.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -95,6 +96,11 @@ struct sncal_hrnet {
     int head_direct_coff = 0, head_direct_c = 0, head_hp = 0, head_m2 = 0;
     int head_k = 0, head_ks1 = 2;     // stage-1 K of the fused head (direct + folded branch channels), its k-steps
     bool fused_enabled = true, use_fused = false;
+    // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
+    bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
+    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
+    std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
+    int n_cus = 0;
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
@@ -532,6 +538,8 @@ inline bool op_active(const sncal_hrnet& net, const Op& op) {
 
 int layout(sncal_hrnet& net, int sb, int H, int W) {
     if (net.lay_sb == sb && net.lay_h == H && net.lay_w == W) return SNCAL_OK;
+    for (auto& kv : net.tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
+    net.tt_plans.clear();
     std::vector<Tensor>& T = net.tensors;
     {   // does the fused head apply?  (bf16 path; the direct tensor must already sit at head resolution)
         auto half = [](int v) { return (v + 2 - 3) / 2 + 1; };
@@ -709,7 +717,7 @@ void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVarian
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
-    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride, bestv->ni, L.mi, L.g);
+    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride, bestv ? bestv->ni : 0, L.mi, L.g);
     static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
     if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
     const double px = (double)sb * to.H * to.W;
@@ -719,8 +727,129 @@ void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVarian
                       (double)L.cout * L.cin * L.k * L.k * net.esize;
 }
 
+// ---- two-team persistent kernel for the wide 3x3 stride-1 convolutions (conv_tt.hip) --------------------------------
+bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb) {
+    if (!net.use_conv_tt || net.dtype != SNCAL_BF16 || op.type != OP_CONV || op.out_f32) return false;
+    const ConvLayer& L = net.layers[op.conv];
+    const Tensor& ti = net.tensors[op.in];
+    const Tensor& to = net.tensors[op.out];
+    if (L.k != 3 || L.stride != 1 || L.mi != 6 || L.g != 4) return false;          // shares the generic kernel's (MI = 6, G = 4) packing
+    if (L.cin != L.cin_phys || L.cin % TT_CIN || L.cout % TT_COUT || L.cout > 480 || ti.C != L.cin) return false;
+    if (to.C % 8 || op.out_coff % 8) return false;
+    const size_t in_bytes = (size_t)sb * ti.H * ti.W * ti.C * 2, out_elems = (size_t)sb * to.H * to.W * to.C;
+    return in_bytes < (1u << 31) && out_elems < (1ull << 32) && (size_t)L.nblk * L.chunks * 9 * 6 * 1024 < (1u << 31);
+}
+
+void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember& m) {
+    const ConvLayer& L = net.layers[op.conv];
+    const Tensor& ti = net.tensors[op.in];
+    const Tensor& to = net.tensors[op.out];
+    memset(&m, 0, sizeof(m));
+    m.in = ws + ti.offset; m.out = ws + to.offset; m.res = op.res >= 0 ? ws + net.tensors[op.res].offset : nullptr;
+    m.w = L.d_w; m.bias = L.d_bias;
+    m.N = sb; m.H = ti.H; m.W = ti.W; m.Cin = L.cin; m.chunks = L.cin / TT_CIN;
+    m.cout = L.cout; m.out_cstride = to.C; m.out_coff = op.out_coff; m.relu = op.relu ? 1 : 0;
+    m.w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * m.chunks * 9 * 6 * 1024);
+    m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C * 2);
+    m.hp1_magic = 0xFFFFFFFFu / (unsigned)(ti.H + 1) + 1u;
+}
+
+// Deal the work items of the member convolutions to the 2 * n_wgs teams.  Workgroup b runs on XCD b % 8 (observed
+// dispatch rule, used for speed only): every member's items -- tile-major, the 96-channel blocks of a tile adjacent --
+// are cut into 8 contiguous slices, one per XCD, so that neighbouring tiles (shared halo rows) and the blocks of one
+// tile (same input) meet in one L2; inside an XCD the items go, most expensive member first, to the team with the
+// least work so far (longest-processing-time rule): the teams of a launch finish within one cheap item of each other.
+int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out) {
+    if (!net.n_cus) {
+        int dev = 0, cus = 0;
+        SNCAL_CHECK_HIP(hipGetDevice(&dev));
+        SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        net.n_cus = cus > 0 ? cus : 256;
+    }
+    const int n_wgs = net.n_cus, nteams = 2 * n_wgs;
+    std::vector<std::vector<TTItem>> per_team(nteams);
+    std::vector<uint32_t> load(nteams, 0);
+    std::vector<std::vector<int>> xcd_teams(8);
+    for (int b = 0; b < n_wgs; ++b) { xcd_teams[b % 8].push_back(2 * b); xcd_teams[b % 8].push_back(2 * b + 1); }
+    int order[TT_MAX_MEMBERS] = {0, 1, 2};
+    std::sort(order, order + n, [&](int a, int b) { return mem[a].chunks > mem[b].chunks; });
+    size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oi = 0; oi < n; ++oi) {
+        const TTMember& m = mem[order[oi]];
+        const int tiles_y = (m.N * (m.H + 1) + TT_TH - 1) / TT_TH, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = m.cout / TT_COUT;
+        const long total = (long)tiles_y * tiles_x * nblk;
+        for (long i = 0; i < total; ++i) {
+            const int x = (int)(i * 8 / total);
+            const std::vector<int>& tl = xcd_teams[x];
+            if (tl.empty()) continue;
+            size_t best = cursor[x] % tl.size();
+            for (size_t k = 0; k < tl.size(); ++k) {      // least loaded, scanning from the rotating cursor
+                const size_t cand = (cursor[x] + k) % tl.size();
+                if (load[tl[cand]] < load[tl[best]]) best = cand;
+            }
+            cursor[x] = best + 1;
+            TTItem it;
+            it.member = (uint16_t)order[oi]; it.nb = (uint16_t)(i % nblk);
+            const long tile = i / nblk;
+            it.col0 = (int32_t)(tile % tiles_x) * TT_TW; it.row0 = (int32_t)(tile / tiles_x) * TT_TH; it.pad_ = 0;
+            per_team[tl[best]].push_back(it);
+            load[tl[best]] += (uint32_t)m.chunks;
+        }
+    }
+    // (Interleaving the members' items inside a team, so that the memory-heavy 96-channel tiles do not all run at the tail of
+    // the launch, measured 1.4 % SLOWER than member after member: 193.3 vs 190.6 us per grouped launch.)
+    std::vector<TTItem> flat;
+    std::vector<uint32_t> first(nteams + 1, 0);
+    for (int t = 0; t < nteams; ++t) { first[t] = (uint32_t)flat.size(); flat.insert(flat.end(), per_team[t].begin(), per_team[t].end()); }
+    first[nteams] = (uint32_t)flat.size();
+    if (flat.empty()) flat.push_back(TTItem{0, 0, 0, 0, 0});
+    SNCAL_CHECK_HIP(hipMalloc((void**)&out.items, flat.size() * sizeof(TTItem)));
+    SNCAL_CHECK_HIP(hipMalloc((void**)&out.first, first.size() * 4));
+    SNCAL_CHECK_HIP(hipMalloc((void**)&out.stages, load.size() * 4));
+    SNCAL_CHECK_HIP(hipMemcpy(out.items, flat.data(), flat.size() * sizeof(TTItem), hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(out.first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    SNCAL_CHECK_HIP(hipMemcpy(out.stages, load.data(), load.size() * 4, hipMemcpyHostToDevice));
+    out.n_wgs = n_wgs;
+    return SNCAL_OK;
+}
+
+// the ops [ops, ops + n) (independent, all eligible) as ONE launch of the two-team kernel
+int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* ws, hipStream_t stream) {
+    TTParams tp;
+    memset(&tp, 0, sizeof(tp));
+    for (int i = 0; i < n; ++i) tt_member(net, ops[i], sb, ws, tp.m[i]);
+    auto it = net.tt_plans.find(key);
+    if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
+        sncal_hrnet::TTPlanDev pd;
+        const int rc = tt_build_plan(net, tp.m, n, pd);
+        if (rc) return rc;
+        it = net.tt_plans.insert({key, pd}).first;
+    }
+    tp.items = it->second.items; tp.team_first = it->second.first; tp.team_stages = it->second.stages;
+    // tuning aid: SNCAL_TT_TRACE=<file> dumps the per-team phase timestamps of the LAST launch with 3 members
+    static const char* trace_file = getenv("SNCAL_TT_TRACE");
+    unsigned long long* d_trace = nullptr;
+    const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
+    if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
+    launch_conv_tt(tp, it->second.n_wgs, stream);
+    SNCAL_CHECK_LAUNCH();
+    if (d_trace) {
+        std::vector<unsigned long long> h(n_trace);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_trace, n_trace * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_trace, f); fclose(f); }
+    }
+    if (net.profiling) {
+        for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
+        net.last_kernel = "conv_tt<bf16,k3,s1,8x32x96>";
+    }
+    return SNCAL_OK;
+}
+
 int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t stream) {
     const ConvLayer& L = net.layers[op.conv];
+    if (tt_eligible(net, op, sb)) return run_conv_tt(net, &op, 1, (int)(&op - net.ops.data()) * 4096 + sb, sb, ws, stream);
     ConvParams p;
     const ConvVariant* bestv = nullptr;
     size_t best_lds = 0;
@@ -751,6 +880,15 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
 int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hipStream_t stream, bool* done) {
     *done = false;
     if (n < 2 || n > 3) return SNCAL_OK;
+    {
+        bool all_tt = true;
+        for (int i = 0; i < n; ++i) all_tt = all_tt && tt_eligible(net, ops[i], sb);
+        if (all_tt) {
+            const int rc = run_conv_tt(net, ops, n, (int)(ops - net.ops.data()) * 4096 + sb, sb, ws, stream);
+            *done = rc == SNCAL_OK;
+            return rc;
+        }
+    }
     ConvGroupParams gp;
     memset(&gp, 0, sizeof(gp));
     const ConvVariant* v0 = nullptr;
@@ -815,6 +953,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
+    for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     for (void* q : {net->d_hw0, net->d_hw1, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);

@@ -176,6 +176,7 @@ def test_grouped_branch_convs_are_bit_identical(sncal, cuda, monkeypatch):
     sd = hr.seeded_state_dict(cfg, 2, 1.5)
     x = hr.seeded_input(2, 540, 960, 9).to(cuda)
     outs, launches = [], []
+    monkeypatch.setenv('SNCAL_CONV_TT', '0')       # the generic kernel's grouping (the two-team kernel has its own test below)
     for flag in ('1', '0'):
         monkeypatch.setenv('SNCAL_GROUP_CONVS', flag)
         net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
@@ -189,6 +190,30 @@ def test_grouped_branch_convs_are_bit_identical(sncal, cuda, monkeypatch):
         assert abs(flops / (2 * 2 * 253910384640) - 1) < 0.3          # accounting still covers every conv (2 frames; fused head counts fewer)
     assert torch.equal(outs[0], outs[1])
     assert launches[0] < launches[1], launches
+
+
+@pytest.mark.parametrize('hw,batch', [((540, 960), 3), ((270, 480), 5), ((1080, 1920), 1)])
+def test_two_team_conv_kernel_is_bit_identical_to_the_generic_kernel(sncal, cuda, monkeypatch, hw, batch):
+    """conv_tt.hip (wide 3x3 stride-1 convolutions: two teams of four waves alternate LDS-DMA and MFMA phases, frames
+    stacked with a shared zero row, swizzled halo image) keeps the generic kernel's packed weights, k-order and epilogue
+    arithmetic: the bf16 network output must not change by one bit.  Batches > 1 put frame boundaries inside tiles; the
+    odd sizes (135/68/34/17 rows, 17x30 at 270x480 input -> 9x15) exercise the partial tiles."""
+    cfg = hr.load_config('hrnet_w48')
+    sd = hr.seeded_state_dict(cfg, 2, 1.5)
+    x = hr.seeded_input(batch, hw[0], hw[1], 9).to(cuda)
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SNCAL_CONV_TT', flag)
+        net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+        net.load_state_dict(sd)
+        net.set_profiling(True)
+        heat, _ = net.forward(x, want_heat=True)
+        prof = {p['kernel']: p for p in net.get_profile()}
+        assert ('conv_tt<bf16,k3,s1,8x32x96>' in prof) == (flag == '1'), sorted(prof)
+        assert ('conv<bf16,k3,s1,NI3,MI6,G4>' in prof) == (flag == '0'), sorted(prof)
+        outs.append(heat.clone())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_frames_are_independent_of_batch_size_and_position(sncal, cuda):

@@ -2,8 +2,12 @@
 //
 // Replaces, for these layers, the conv3x3 + eval-BN (+ residual) (+ ReLU) of BasicBlock
 // (/root/reference/src/models/hrnet/hrnet.py:42-58) that the generic kernel (conv.hpp) runs as
-// conv<bf16,k3,s1,NI3,MI6,G4>.  Same GEMM view, same packed weights, same k-order (chunk of 32 input channels ->
-// tap -> 8-channel group) and the same epilogue arithmetic, so the outputs are BIT-IDENTICAL to the generic kernel.
+// conv<bf16,k3,s1,NI3,MI6,G4>.  Same GEMM view (D[cout, pixel] = sum_k W[cout, k] X[k, pixel], k = chunk of 32 input
+// channels -> tap -> channel), same bf16 operands, fp32 accumulation started at the folded-BN shift, same epilogue
+// arithmetic.  The MFMA shape is v_mfma_f32_32x32x16_bf16 (the generic kernel: 16x16x32): the products of one output are
+// summed in a different order inside the matrix unit, so outputs agree with the generic kernel to fp32 rounding of the
+// accumulator, not bit for bit (the first version of this kernel used 16x16x32 and WAS bit-identical; a phase trace
+// showed 216 of them take 4.1k clk per wave where 108 of the 32x32x16 take 3.5k -- MI355X_MICROARCH.md: 2075 vs 2382 TF).
 //
 // Why another kernel.  The generic kernel stages a chunk (54 KB of weights + the halo tile), waits, multiplies, and
 // relies on a second resident workgroup to fill the wait.  Measured: the two workgroups drift into
@@ -24,8 +28,8 @@
 // bottom padding of frame f and the top padding of frame f + 1).  Tiles of 8 stacked rows then cut the whole batch with
 // 1 / (H + 1) waste instead of (ceil(H / 8) * 8 - H) / H per frame -- 6 % instead of 41 % on the 17 x 30 branch.
 // The halo image in LDS is [pixel][4 x 16 B] at a 36-pixel row pitch with the four 8-channel groups of a pixel rotated
-// by 2 * ((pixel >> 2) & 1): every ds_read_b128 lane group of a B fragment then touches 16 distinct 16-byte bank
-// slots (enumerated against MI355X_MICROARCH.md "LDS"), without the 50 % pitch padding of the generic kernel; the
+// by (pixel >> 2) & 3: every ds_read_b128 lane group of a B fragment (32 consecutive pixels, one channel group per
+// half-wave) then touches 16 distinct 16-byte bank slots (enumerated against MI355X_MICROARCH.md "LDS"), without the 50 % pitch padding of the generic kernel; the
 // rotation is applied on the DMA's per-lane SOURCE address, the LDS destination stays lane-linear.
 // Work items (tile x 96-channel block, cost = Cin / 32 stages) of up to three member convolutions are dealt to the
 // 2 x 256 teams on the host (conv_tt_plan in hrnet.cpp): contiguous slices per XCD, longest-processing-time first.
@@ -36,27 +40,30 @@ namespace sncal {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 
 namespace {
-constexpr int MI = 6, NI = 4, NKS = 9;
+constexpr int MB = 3, NB = 2, NT = 18;              // 32-channel blocks, 32-pixel blocks (= tile rows) per wave, K = 16 steps per stage
+constexpr int NKS = 9, MI = 6;                      // taps; 1 KB weight pieces per tap
 constexpr int W_BYTES = NKS * MI * 1024;            // 55296: one stage of weights, fragment order [k-step][mi][lane] x 16 B
 constexpr int HP = 36;                              // halo row pitch in pixels (34 used)
 constexpr int HROWS = TT_TH + 2;                    // 10
 constexpr int HALO_PIECES = (HROWS * HP * 64 + 1023) / 1024;    // 23 DMA pieces of 1 KB
 constexpr int H_BYTES = HALO_PIECES * 1024;         // 23552
 constexpr int TEAM_BYTES = W_BYTES + H_BYTES;       // 78848; two teams = 157696 B of the CU's 163840
-constexpr int WPW = 14;                             // weight pieces per wave: wave tw owns pieces [14 tw, 14 tw + 14) of the 54 -- a
-                                                    // CONTIGUOUS block, because the wave also stages its epilogue there (below)
+// weight pieces per wave: wave tw owns pieces [wp_first(tw), wp_first(tw + 1)) of the 54 = 14, 14, 13, 13 -- a CONTIGUOUS
+// block, because the wave also stages its epilogue there (below)
+__device__ __host__ constexpr int wp_first(int tw) { return tw * 14 - (tw > 3 ? 2 : tw > 2 ? 1 : 0); }
 constexpr int BIAS_MAX = 480;                         // output channels per member the LDS bias table holds (5 blocks of 96)
 constexpr int EPI_PITCH = TT_COUT + 4;              // floats per staged pixel row
-constexpr int EPI_GROUPS = TT_COUT / 8, EPI_ITEMS = 16 * EPI_GROUPS, EPI_ITERS = (EPI_ITEMS + 63) / 64;   // 12, 192, 3
-static_assert(16 * EPI_PITCH * 4 <= (NKS * MI - 3 * WPW) * 1024, "a wave's epilogue staging must fit its own block of the weight region");
+constexpr int EPI_GROUPS = TT_COUT / 8, EPI_ITEMS = 32 * EPI_GROUPS, EPI_ITERS = EPI_ITEMS / 64;   // 12, 384, 6
+static_assert(wp_first(4) == NKS * MI && 32 * EPI_PITCH * 4 <= 13 * 1024, "a wave's epilogue staging must fit its own block of the weight region");
 }  // namespace
 
 __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, ln = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = wv >> 2, tw = wv & 3;
     const unsigned T = blockIdx.x * 2u + (unsigned)team;
@@ -67,34 +74,44 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     unsigned it = P.team_first[T];
     const unsigned SA = P.team_stages[blockIdx.x * 2u], SB = P.team_stages[blockIdx.x * 2u + 1u];
 
-    // B-fragment base offsets inside the halo region for tap column dx and row parity rp (see header): everything else
-    // of a fragment address is a compile-time immediate of the ds_read
-    const char* bptr[3][2];
+    // B fragment of K = 16 step (tap (dy, dx), channel half h) for tile row jr of this wave: pixel (tw * 2 + jr + dy, l31 + dx),
+    // channel group cg = 2 h + hi, stored in slot (rot + cg) & 3 with rot = (pixel >> 2) & 3 = (row + ((l31 + dx) >> 2)) & 3
+    // (row pitch 36 = 9 * 4).  bptr[dx][k] carries everything that depends on the lane for k = (jr + dy + 2 h) & 3; the rest of
+    // the address, (jr + dy) * 36 * 64, is an immediate of the ds_read.
+    const char* bptr[3][4];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int rp = 0; rp < 2; ++rp)
-            bptr[dx][rp] = s_h + ((tw * 2 * HP + ln + dx) * 64 + ((2 * ((((ln + dx) >> 2) + rp) & 1) + g) & 3) * 16);
+        for (int k = 0; k < 4; ++k)
+            bptr[dx][k] = s_h + ((tw * 2 * HP + l31 + dx) * 64 + ((tw * 2 + ((l31 + dx) >> 2) + hi + k) & 3) * 16);
     const char* const aptr = s_w + lane * 16;
 
+    unsigned long long* const trc = P.trace ? P.trace + (size_t)T * 256 : nullptr;
+    unsigned tix = 0, eix = 192;          // [0,192): six stamps per stage; [192,256): four stamps per epilogue
+    auto stamp = [&]() { if (trc && tid == team * 256 && tix < 192) trc[tix++] = __builtin_amdgcn_s_memtime(); };
+    auto estamp = [&]() { if (trc && tid == team * 256 && eix < 256) trc[eix++] = __builtin_amdgcn_s_memtime(); };
+
     // ---- state of the team's current item ---------------------------------------------------------------------------
-    // While the partner wave of the SIMD issues MFMAs, a VALU instruction of the loading wave issues only every 5-8 clk
-    // (phase traces, tools/tt_trace.py): per-lane address arithmetic is the expensive part of a LOAD phase.  So the halo
-    // offsets are computed once per item (not per stage), and the epilogue's addresses are split into a wave-uniform
-    // scalar part (row, tile column, channel block: SALU) and three per-lane constants.
-    f32x4 acc[MI][NI];
+    // Beside a multiplying partner wave, a dependent VALU instruction of the loading wave completes every 5-8 clk and a
+    // vector-memory instruction costs ~160 clk (phase traces, tools/tt_trace.py): per-lane address arithmetic and the 24
+    // loads / stores of an epilogue are the expensive parts of a LOAD phase.  So the halo offsets are computed once per
+    // item (not per stage), and the epilogue's addresses are split into a wave-uniform scalar part (row, tile column,
+    // channel block: SALU) and per-lane constants.
+    f32x16 acc[MB][NB];
     unsigned hv[6];                       // per-lane byte offsets of this wave's halo DMA pieces (stage-independent)
     TTMember M = P.m[0];
     int nb = 0, c = 0, row0 = 0, col0 = 0;
 
     // byte offset of this lane's 16 bytes of halo piece `piece`: slot q of the [pixel][4] image holds channel group
-    // (q & 3) - 2 * ((pixel >> 2) & 1); pitch padding, rows / columns outside the frame and the shared zero row between
-    // stacked frames get an out-of-range offset -> the DMA writes zeros
+    // (q & 3) - (pixel >> 2) mod 4; pitch padding, rows / columns outside the frame and the shared zero row between
+    // stacked frames get an out-of-range offset -> the DMA writes zeros.  (Splitting this into per-lane kernel constants and
+    // a wave-uniform scalar part per item -- 42 instead of ~200 VALU instructions -- was built and measured SLOWER: the
+    // scalar part pushed the kernel over the 102-SGPR budget and the spills cost more than the VALU work saved.)
     auto halo_voff = [&](int piece, int lane) -> unsigned {
         const unsigned q = (unsigned)(piece * 64 + lane);
         const unsigned p = q >> 2;
         const unsigned hrow = (p * 1821u) >> 16, hcol = p - hrow * HP;           // p / 36 for p < 2048
-        const unsigned cg = ((q & 3u) - 2u * ((p >> 2) & 1u)) & 3u;
+        const unsigned cg = ((q & 3u) - (p >> 2)) & 3u;
         const int s = row0 - 1 + (int)hrow;
         const unsigned f = __umulhi((unsigned)max(s, 0), M.hp1_magic);
         const int y = s - (int)f * (M.H + 1);
@@ -112,24 +129,30 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         asm volatile("" : "+v"(lane_l));
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) hv[jj] = tw + 4 * jj < HALO_PIECES ? halo_voff(tw + 4 * jj, lane_l) : 0x80000000u;
-        // accumulators start at the folded-BN shift of the lane's 4 output channels.  The shifts come from a table in LDS
-        // (filled once per workgroup): a global load here would sit behind the old tile's stores and its wait, vmcnt(0),
-        // would last until every store has drained (3-5k clk under load, traced)
-        const float* const bt = s_bias + I.member * BIAS_MAX + nb * TT_COUT + g * 4;
+        if (eix > 192) estamp();
+        // accumulators start at the folded-BN shift: register quad q of block mb holds channels mb * 32 + 8 q + 4 hi + 0..3 of
+        // pixel l31.  The shifts come from a table in LDS (filled once per workgroup): a global load here would sit behind the
+        // old tile's stores and its wait, vmcnt(0), would last until every store has drained
+        const float* const bt = s_bias + I.member * BIAS_MAX + nb * TT_COUT + 4 * hi;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const float4 bs = *reinterpret_cast<const float4*>(bt + mi * 16);
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[mi][j] = f32x4{bs.x, bs.y, bs.z, bs.w};
-        }
+            for (int q = 0; q < 4; ++q) {
+                const float4 bs = *reinterpret_cast<const float4*>(bt + mb * 32 + 8 * q);
+#pragma unroll
+                for (int jr = 0; jr < NB; ++jr) {
+                    acc[mb][jr][4 * q + 0] = bs.x; acc[mb][jr][4 * q + 1] = bs.y; acc[mb][jr][4 * q + 2] = bs.z; acc[mb][jr][4 * q + 3] = bs.w;
+                }
+            }
     };
 
+    auto setup_done_stamp = [&]() { if (eix > 192) estamp(); };
     auto issue_stage = [&](int cc) {
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.in), 0, (int)M.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.w), 0, (int)M.w_bytes, 0x00020000);
         const unsigned wbase = (unsigned)((nb * M.chunks + cc) * W_BYTES);
-        const int i1 = min(tw * WPW + WPW, NKS * MI);
-        for (int i = tw * WPW; i < i1; ++i)
+        const int i1 = wp_first(tw + 1);
+        for (int i = wp_first(tw); i < i1; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(s_w + i * 1024), 16, (unsigned)(lane * 16), wbase + i * 1024, 0, 0);
         const unsigned cbase = (unsigned)(cc * 64);
 #pragma unroll
@@ -137,11 +160,6 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
             if (tw + 4 * jj < HALO_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(s_h + (tw + 4 * jj) * 1024), 16, hv[jj], cbase, 0, 0);
     };
-
-    unsigned long long* const trc = P.trace ? P.trace + (size_t)T * 256 : nullptr;
-    unsigned tix = 0, eix = 192;          // [0,192): six stamps per stage; [192,256): four stamps per epilogue
-    auto stamp = [&]() { if (trc && tid == team * 256 && tix < 192) trc[tix++] = __builtin_amdgcn_s_memtime(); };
-    auto estamp = [&]() { if (trc && tid == team * 256 && eix < 256) trc[eix++] = __builtin_amdgcn_s_memtime(); };
 
     // (+ residual) (ReLU) -> bf16, through a wave-private LDS transpose so that every lane stores 8 consecutive channels.
     // BRANCH-FREE: residual loads and output stores go through buffer descriptors, an item with nothing to store carries an
@@ -154,8 +172,9 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                                                                                   M.res ? (int)out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(M.out, 0, (int)out_bytes, 0x00020000);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        estamp();
-        // item e of a fragment: lane -> pixel px of the fragment's 16 and 8-channel group grp (lane constants of the kernel)
+        const bool has_res = M.res != nullptr;      // the first conv of a BasicBlock has none: no loads, no unpack / add (a VALU
+        estamp();                                   // instruction beside a multiplying partner costs ~8 clk, a load ~160)
+        // item e of a tile row: lane -> pixel px of the row's 32 and 8-channel group grp (lane constants of the kernel)
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
         unsigned lane_off[EPI_ITERS];
@@ -167,42 +186,45 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
             px_e[e] = px;
             lane_off[e] = (unsigned)((px * M.out_cstride + grp * 8) * 2);
         }
-        u32x4 rr[NI][EPI_ITERS];
-        unsigned voff[NI][EPI_ITERS], soff[NI];
+        u32x4 rr[NB][EPI_ITERS];
+        unsigned voff[NB][EPI_ITERS], soff[NB];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            // wave-uniform part (SALU): stacked row -> (frame, row), first pixel of the fragment, channel block
-            const int fx = j & 1;
-            const int srow = row0 + tw * 2 + (j >> 1);
+        for (int jr = 0; jr < NB; ++jr) {
+            // wave-uniform part (SALU): stacked row -> (frame, row), channel block
+            const int srow = row0 + tw * 2 + jr;
             const unsigned f = __umulhi((unsigned)srow, M.hp1_magic);
             const int y = srow - (int)f * (M.H + 1);
             const bool row_ok = ((int)f < M.N) & (y < M.H);
-            const int x0 = col0 + fx * 16;
-            soff[j] = row_ok ? (unsigned)(((((int)f * M.H + y) * M.W + x0) * M.out_cstride + M.out_coff + nb * TT_COUT) * 2) : 0u;
+            soff[jr] = row_ok ? (unsigned)(((((int)f * M.H + y) * M.W + col0) * M.out_cstride + M.out_coff + nb * TT_COUT) * 2) : 0u;
 #pragma unroll
             for (int e = 0; e < EPI_ITERS; ++e) {
-                voff[j][e] = (row_ok & (px_e[e] < M.W - x0)) ? lane_off[e] : 0x80000000u;      // out of range: loads 0, stores nothing
-                rr[j][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff[j][e], soff[j], 0);
+                voff[jr][e] = (row_ok & (px_e[e] < M.W - col0)) ? lane_off[e] : 0x80000000u;      // out of range: loads 0, stores nothing
+                rr[jr][e] = u32x4{0u, 0u, 0u, 0u};
+                if (has_res) rr[jr][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff[jr][e], soff[jr], 0);     // wave-uniform branch
             }
         }
-        float* const stg = reinterpret_cast<float*>(s_w + tw * WPW * 1024);      // this wave's own block of the weight region
+        float* const stg = reinterpret_cast<float*>(s_w + wp_first(tw) * 1024);      // this wave's own block of the weight region
         estamp();
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (j == 1) estamp();
+        for (int jr = 0; jr < NB; ++jr) {
+            if (jr == 1) estamp();
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                *reinterpret_cast<float4*>(stg + ln * EPI_PITCH + mi * 16 + g * 4) =
-                    make_float4(acc[mi][j][0], acc[mi][j][1], acc[mi][j][2], acc[mi][j][3]);
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(stg + l31 * EPI_PITCH + mb * 32 + 8 * q + 4 * hi) =
+                        make_float4(acc[mb][jr][4 * q], acc[mb][jr][4 * q + 1], acc[mb][jr][4 * q + 2], acc[mb][jr][4 * q + 3]);
             // wave-local hand-off: the LDS operations of one wave complete in order
 #pragma unroll
             for (int e = 0; e < EPI_ITERS; ++e) {
                 const float* sp = stg + (lane_off[e] >> 1) - px_e[e] * (M.out_cstride - EPI_PITCH);     // px * PITCH + grp * 8
-                const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const bf16x8 r = __builtin_bit_cast(bf16x8, rr[j][e]);
+                const float4 lo = *reinterpret_cast<const float4*>(sp), hi4 = *reinterpret_cast<const float4*>(sp + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (has_res) {
+                    const bf16x8 r = __builtin_bit_cast(bf16x8, rr[jr][e]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
+                    for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
+                }
                 bf16x8 q;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) q[k] = (__bf16)v[k];
@@ -211,58 +233,65 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     q = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), z));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs_out, voff[j][e], soff[j], 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs_out, voff[jr][e], soff[jr], 0);
             }
         }
         estamp();
     };
 
-    auto multiply_stage = [&]() {
-        bf16x8 a[2][MI], b[2][NI];
-        auto load_frags = [&](int s, int buf) {
-            const int dy = s / 3, dx = s - dy * 3;
+    // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t multiplies.
+    // `near_end` runs before the last two steps (the token is handed on while ~400 clk of MFMAs are still queued).
+    auto multiply_stage = [&](auto&& near_end) {
+        bf16x8 a[2][MB], b[2][NB];
+        auto load_frags = [&](int t, int buf) {
+            const int s = t >> 1, h = t & 1, dy = s / 3, dx = s - dy * 3;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[buf][mi] = *reinterpret_cast<const bf16x8*>(aptr + (s * MI + mi) * 1024);
+            for (int mb = 0; mb < MB; ++mb) a[buf][mb] = *reinterpret_cast<const bf16x8*>(aptr + (t * MB + mb) * 1024);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = (j >> 1) + dy;
-                b[buf][j] = *reinterpret_cast<const bf16x8*>(bptr[dx][r & 1] + (r * HP + (j & 1) * 16) * 64);
-            }
+            for (int jr = 0; jr < NB; ++jr)
+                b[buf][jr] = *reinterpret_cast<const bf16x8*>(bptr[dx][(jr + dy + 2 * h) & 3] + (jr + dy) * HP * 64);
         };
         // pin the accumulators where they are: without this hipcc copies the 96 registers on entry (two reaching
-        // definitions: the bias of a new item / the previous stage) and spills six of the originals around the phase
+        // definitions: the bias of a new item / the previous stage) and spills some of the originals around the phase
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[mi][j]));
+            for (int jr = 0; jr < NB; ++jr) asm volatile("" : "+v"(acc[mb][jr]));
         load_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < NKS) load_frags(s + 1, cur ^ 1);
+        for (int t = 0; t < NT; ++t) {
+            const int cur = t & 1;
+            if (t == NT - 2) near_end();
+            if (t + 1 < NT) {
+                load_frags(t + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);                 // ... and keep the reads ABOVE this step's MFMAs: hipcc otherwise sinks
+            }                                                      // them below five of the six (register reuse) and every step waits for LDS
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mi], b[cur][j], acc[mi][j], 0, 0, 0);
-            if (s + 1 < NKS) __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the next step's MFMAs
+                for (int jr = 0; jr < NB; ++jr)
+                    acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mb], b[cur][jr], acc[mb][jr], 0, 0, 0);
+            if (t + 1 < NT) __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the next step's MFMAs
         }
     };
 
     // Both teams run the same program -- per stage: LOAD (DMA, and at an item boundary the previous tile's epilogue), team
-    // barrier, take the CU's MULTIPLY token, 216 MFMAs per wave, release.  The token makes the MFMA phases of the two teams
+    // barrier, take the CU's MULTIPLY token, 108 MFMAs per wave, release.  The token makes the MFMA phases of the two teams
     // mutually exclusive (two multiplying waves on one SIMD would only halve each other), so the teams alternate by
     // themselves: while one multiplies the other loads.  They are NOT locked phase by phase: the first version closed every
     // phase with one s_barrier over both teams, and a team whose LOAD phase carried an epilogue (~6k clk: 24 vector-memory
     // instructions per wave at ~160 clk each beside a multiplying partner) held the partner's next multiply back by 2-5k
     // clk per tile.  Now the partner takes the token again as soon as its own next stage has landed.
-    // Team-level synchronisation goes through four LDS words (one wave-instruction each way, s_sleep while polling):
-    //   arrive  += 1 per wave when its DMA pieces have landed          go   = k + 1 once wave 0 holds the token
-    //   done    += 1 per wave when its MFMAs (and LDS reads) are over; the last one frees the token
-    unsigned* const ctrl = reinterpret_cast<unsigned*>(smem + 2 * TEAM_BYTES);       // [0] token, [4 + 4 team + {0,1,2}] arrive, go, done
+    // Team-level synchronisation goes through LDS words (one wave-instruction each way, s_sleep while polling):
+    //   arrive += 1 per wave when its DMA pieces have landed            go    = k + 1 once wave 0 holds the token
+    //   early  += 1 per wave two K-steps before the end of its MFMAs;   the last one frees the token
+    //   done   += 1 per wave when its MFMAs (and LDS reads) are over:   the stage's buffers may be overwritten
+    unsigned* const ctrl = reinterpret_cast<unsigned*>(smem + 2 * TEAM_BYTES);       // [0] token, [4 + 4 team + {0,1,2,3}] arrive, go, done, early
     unsigned* const w_token = ctrl;
     unsigned* const w_arrive = ctrl + 4 + 4 * team;
     unsigned* const w_go = w_arrive + 1;
     unsigned* const w_done = w_arrive + 2;
+    unsigned* const w_early = w_arrive + 3;
     if (tid < 16) ctrl[tid] = 0u;
 #pragma unroll
     for (int m = 0; m < TT_MAX_MEMBERS; ++m)
@@ -281,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         if (c == 0) {
             if (st > 0) epilogue();                               // the finished tile, out of registers that the new one needs
             setup_item(I_next);
+            setup_done_stamp();
             // the item after this one is fetched now (a scalar load that misses every cache: 2-3k clk if waited for on the spot)
             I_next = P.items[min(it + 1u, it_last)];
         }
@@ -307,14 +337,15 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         }
         asm volatile("" ::: "memory");
         stamp();                                                  // [4] MULTIPLY begins
-        multiply_stage();
+        multiply_stage([&]() {
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(w_early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && old == 4u * st + 3u) __hip_atomic_store(w_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
         if (++c == M.chunks) { c = 0; ++it; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp();                                                  // [5] MFMAs issued
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(w_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old == 4u * st + 3u && lane == 0) __hip_atomic_store(w_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(w_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         spin_until(w_done, 4u * (st + 1u));                       // every wave of the team is done reading this stage
     }
     if (S > 0) { epilogue(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

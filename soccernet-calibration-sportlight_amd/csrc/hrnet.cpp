@@ -43,6 +43,7 @@ struct ConvLayer {
     int cin_phys = 0, mi = 0, g = 0, chunks = 0, nblk = 0, cout_frags = 0;
     void* d_w = nullptr;
     float* d_bias = nullptr;
+    void* d_w_tt = nullptr;     // second packing, for the two-team kernel (conv_tt.hip): 32 x 32 x 16 MFMA fragment order
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
@@ -480,6 +481,37 @@ int pack_layer(sncal_hrnet& net, ConvLayer& L) {
     return SNCAL_OK;
 }
 
+// Packing of a wide 3x3 stride-1 layer for the two-team kernel (conv_tt.hip): per (96-channel block nb, 32-channel chunk c)
+// one 54 KB stage [tap 9][channel half 2][32-row block 3][lane 64] x 8 bf16, the A fragments of v_mfma_f32_32x32x16_bf16:
+// lane l holds output channel nb * 96 + mb * 32 + (l & 31), input channels c * 32 + h * 16 + (l >> 5) * 8 + 0..7 of the tap.
+bool tt_shape_ok(const sncal_hrnet& net, const ConvLayer& L) {
+    return net.dtype == SNCAL_BF16 && L.k == 3 && L.stride == 1 && L.cin == L.cin_phys && L.cin % TT_CIN == 0 &&
+           L.cout % TT_COUT == 0 && L.cout <= 480;
+}
+
+int pack_layer_tt(sncal_hrnet& net, ConvLayer& L) {
+    if (L.d_w_tt) { (void)hipFree(L.d_w_tt); L.d_w_tt = nullptr; }
+    if (!tt_shape_ok(net, L)) return SNCAL_OK;
+    const int chunks = L.cin / TT_CIN, nblk = L.cout / TT_COUT;
+    std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 2 * 3 * 64 * 8, 0);
+    for (int nb = 0; nb < nblk; ++nb)
+        for (int c = 0; c < chunks; ++c)
+            for (int s = 0; s < 9; ++s)
+                for (int h = 0; h < 2; ++h)
+                    for (int mb = 0; mb < 3; ++mb)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = nb * TT_COUT + mb * 32 + (lane & 31);
+                            uint16_t* dst = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + h) * 3 + mb) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const int ci = c * TT_CIN + h * 16 + (lane >> 5) * 8 + e;
+                                dst[e] = f2bf(L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co]);
+                            }
+                        }
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w_tt, host.size() * 2));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w_tt, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    return SNCAL_OK;
+}
+
 // stage-1 / stage-2 A fragments + biases of the fused head (head.hip), bf16 only
 int pack_head(sncal_hrnet& net) {
     if (net.dtype != SNCAL_BF16) return SNCAL_OK;
@@ -733,8 +765,7 @@ bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb) {
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
-    if (L.k != 3 || L.stride != 1 || L.mi != 6 || L.g != 4) return false;          // shares the generic kernel's (MI = 6, G = 4) packing
-    if (L.cin != L.cin_phys || L.cin % TT_CIN || L.cout % TT_COUT || L.cout > 480 || ti.C != L.cin) return false;
+    if (!L.d_w_tt || ti.C != L.cin) return false;                                   // packed at finalize for the eligible shapes
     if (to.C % 8 || op.out_coff % 8) return false;
     const size_t in_bytes = (size_t)sb * ti.H * ti.W * ti.C * 2, out_elems = (size_t)sb * to.H * to.W * to.C;
     return in_bytes < (1u << 31) && out_elems < (1ull << 32) && (size_t)L.nblk * L.chunks * 9 * 6 * 1024 < (1u << 31);
@@ -746,7 +777,7 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
     const Tensor& to = net.tensors[op.out];
     memset(&m, 0, sizeof(m));
     m.in = ws + ti.offset; m.out = ws + to.offset; m.res = op.res >= 0 ? ws + net.tensors[op.res].offset : nullptr;
-    m.w = L.d_w; m.bias = L.d_bias;
+    m.w = L.d_w_tt; m.bias = L.d_bias;
     m.N = sb; m.H = ti.H; m.W = ti.W; m.Cin = L.cin; m.chunks = L.cin / TT_CIN;
     m.cout = L.cout; m.out_cstride = to.C; m.out_coff = op.out_coff; m.relu = op.relu ? 1 : 0;
     m.w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * m.chunks * 9 * 6 * 1024);
@@ -954,7 +985,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     for (void* q : {net->d_hw0, net->d_hw1, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
@@ -1015,7 +1046,9 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         if (!L.is_set) { set_error("conv %s has no weights", L.name.c_str()); return SNCAL_ERR_STATE; }
         choose_packing(*net, L);
         if (L.mi == 0) { set_error("no kernel variant for conv %s (k=%d s=%d)", L.name.c_str(), L.k, L.stride); return SNCAL_ERR_STATE; }
-        const int rc = pack_layer(*net, L);
+        int rc = pack_layer(*net, L);
+        if (rc) return rc;
+        rc = pack_layer_tt(*net, L);
         if (rc) return rc;
         std::vector<float>().swap(L.w);
     }

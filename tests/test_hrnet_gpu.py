@@ -193,27 +193,34 @@ def test_grouped_branch_convs_are_bit_identical(sncal, cuda, monkeypatch):
 
 
 @pytest.mark.parametrize('hw,batch', [((540, 960), 3), ((270, 480), 5), ((1080, 1920), 1)])
-def test_two_team_conv_kernel_is_bit_identical_to_the_generic_kernel(sncal, cuda, monkeypatch, hw, batch):
+def test_two_team_conv_kernel_matches_the_generic_kernel(sncal, cuda, monkeypatch, hw, batch):
     """conv_tt.hip (wide 3x3 stride-1 convolutions: two teams of four waves alternate LDS-DMA and MFMA phases, frames
-    stacked with a shared zero row, swizzled halo image) keeps the generic kernel's packed weights, k-order and epilogue
-    arithmetic: the bf16 network output must not change by one bit.  Batches > 1 put frame boundaries inside tiles; the
-    odd sizes (135/68/34/17 rows, 17x30 at 270x480 input -> 9x15) exercise the partial tiles."""
+    stacked with a shared zero row, swizzled halo image, v_mfma_f32_32x32x16_bf16) against the generic kernel
+    (v_mfma_f32_16x16x32_bf16) on the whole bf16 network.  Same operands, same fp32 accumulation, but the matrix unit sums
+    the products of one output in a different order: outputs agree to accumulator rounding, which the ~300 bf16 layers
+    turn into occasional one-ulp flips -- a few 1e-2 in log-probability at worst, far inside the bf16 engine's distance
+    from the fp32 engine (tests/test_parity_gpu.py).  [The first version of the kernel used the 16x16x32 shape and was
+    bit-identical to the generic kernel on these very cases: tiling, stacking and swizzle are exact.]
+    Batches > 1 put frame boundaries inside tiles; the odd sizes (135/68/34/17 rows, 9x15 at 270x480) exercise partial tiles."""
     cfg = hr.load_config('hrnet_w48')
     sd = hr.seeded_state_dict(cfg, 2, 1.5)
     x = hr.seeded_input(batch, hw[0], hw[1], 9).to(cuda)
-    outs = []
+    outs, kps = [], []
     for flag in ('1', '0'):
         monkeypatch.setenv('SNCAL_CONV_TT', flag)
         net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
         net.load_state_dict(sd)
         net.set_profiling(True)
-        heat, _ = net.forward(x, want_heat=True)
+        heat, kp = net.forward(x, want_heat=True, decode_size=(540, 960))
         prof = {p['kernel']: p for p in net.get_profile()}
         assert ('conv_tt<bf16,k3,s1,8x32x96>' in prof) == (flag == '1'), sorted(prof)
         assert ('conv<bf16,k3,s1,NI3,MI6,G4>' in prof) == (flag == '0'), sorted(prof)
         outs.append(heat.clone())
+        kps.append(kp.clone())
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    d = (outs[0] - outs[1]).abs()
+    assert float(d.max()) <= 0.25 and float(d.mean()) <= 0.01, (float(d.max()), float(d.mean()))
+    assert float((kps[0][..., :2] == kps[1][..., :2]).all(-1).float().mean()) >= 0.9
 
 
 def test_frames_are_independent_of_batch_size_and_position(sncal, cuda):

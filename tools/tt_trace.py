@@ -11,12 +11,13 @@ rows = []
 erows = []
 for team in range(ep.shape[0]):
     v = ep[team][ep[team] > 0]
-    n = len(v) // 4
+    n = len(v) // 6
     if n:
-        erows.append(np.diff(v[:n * 4].reshape(n, 4), axis=1))
+        erows.append(np.diff(v[:n * 6].reshape(n, 6), axis=1))
 if erows:
     e = np.concatenate(erows)
-    for i, nm in enumerate(['epi: residual loads issued', 'epi: fragment 0 (incl. wait for the residual)', 'epi: fragments 1-3']):
+    for i, nm in enumerate(['epi: residual loads issued', 'epi: tile row 0 (incl. wait for the residual)', 'epi: tile row 1',
+                            'setup: halo offsets', 'setup: accumulators from the LDS bias table']):
         print(f'  {nm:48s} median {np.median(e[:, i]):8.0f}  mean {e[:, i].mean():8.0f}  p90 {np.percentile(e[:, i], 90):8.0f}')
 for team in range(t.shape[0]):
     v = t[team][t[team] > 0]

@@ -38,7 +38,7 @@ typedef enum {
     SNCAL_ERR_UNSUPPORTED = -5 /* well-formed input that this build does not handle (e.g. progressive JPEG) */
 } sncal_status;
 
-typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1 } sncal_dtype;
+typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1, SNCAL_FP8 = 2 } sncal_dtype;
 
 int sncal_version(void);
 const char* sncal_last_error(void);
@@ -100,7 +100,9 @@ typedef struct sncal_hrnet sncal_hrnet;
 
 /* Build the execution plan (no weights yet).  dtype selects the arithmetic of the conv kernels:
  * SNCAL_BF16 = bf16 activations/weights with fp32 MFMA accumulation (fast path),
- * SNCAL_F32  = fp32 activations/weights on the exact-fp32 MFMA (parity path). */
+ * SNCAL_F32  = fp32 activations/weights on the exact-fp32 MFMA (parity path),
+ * SNCAL_FP8  = the bf16 engine with OCP e4m3 arithmetic (CDNA4 block-scaled MFMA, K = 64) in the wide 3x3 stride-1
+ *              convolutions of stages 2-4 (BASELINE config 5); needs sncal_hrnet_calibrate_fp8 before the first forward. */
 int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out);
 void sncal_hrnet_destroy(sncal_hrnet* net);
 
@@ -128,6 +130,18 @@ int sncal_hrnet_workspace(const sncal_hrnet* net, int B, int H, int W, size_t* b
 int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat,
                         float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes,
                         void* stream);
+
+/* C5 (BASELINE.json configs[4]: "HRNet-W48 fp8 (CDNA4 fp8 MFMA) 1920x1080 ... reproj-error tolerance sweep").  No reference
+ * counterpart: HRNetMetaModel.predict is fp32 (src/models/hrnet/metamodel.py:127-134); the reference's AMP autocast exists
+ * only in its train / val steps (:34, :67).
+ * calibrate: one bf16 forward of d_x (B,3,H,W) that records max |x| of every tensor feeding an fp8-capable convolution
+ *            (BasicBlock conv1 / conv2 of the 96 / 192 / 384-channel branches, src/models/hrnet/hrnet.py:42-58) ->
+ *            per-tensor activation scales amax / 448; weights carry one scale per output channel.
+ * set_fp8_layers: which of those convolutions run in fp8 -- "all", "none", or a comma list of stage2..stage4 and c<width>
+ *            (a layer is selected when its stage AND its width are selected; an empty class selects all of it).  The
+ *            tolerance sweep of tests/test_fp8_gpu.py walks this selection. */
+int sncal_hrnet_calibrate_fp8(sncal_hrnet* net, const float* d_x, int B, int H, int W, void* d_ws, size_t ws_bytes, void* stream);
+int sncal_hrnet_set_fp8_layers(sncal_hrnet* net, const char* spec);
 
 /* Same forward from the frames as the reference's harness holds them BEFORE torchvision's ToTensor
  * (make_submit.py:62-66: cv2.imread -> BGR uint8 (H,W,3) -> ToTensor = float32 x/255, CHW): d_x (B,H,W,3) uint8.

@@ -83,6 +83,8 @@ SIGNATURES = {
     'sncal_hrnet_forward_u8': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
                                               ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     'sncal_hrnet_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
+    'sncal_hrnet_calibrate_fp8': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    'sncal_hrnet_set_fp8_layers': (ctypes.c_int, [vp, ctypes.c_char_p]),
     'sncal_hrnet_get_profile': (ctypes.c_int, [vp, ctypes.POINTER(KernelStat), ctypes.c_int, c_int_p]),
     'sncal_pnp_refine_lm': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                            ctypes.c_double, vp]),

@@ -35,12 +35,15 @@
 // 2 x 256 teams on the host (conv_tt_plan in hrnet.cpp): contiguous slices per XCD, longest-processing-time first.
 #include "common.hpp"
 #include "conv_tt.hpp"
+#include <cstddef>
 
 namespace sncal {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
 namespace {
@@ -55,12 +58,36 @@ constexpr int TEAM_BYTES = W_BYTES + H_BYTES;       // 78848; two teams = 157696
 // weight pieces per wave: wave tw owns pieces [wp_first(tw), wp_first(tw + 1)) of the 54 = 14, 14, 13, 13 -- a CONTIGUOUS
 // block, because the wave also stages its epilogue there (below)
 __device__ __host__ constexpr int wp_first(int tw) { return tw * 14 - (tw > 3 ? 2 : tw > 2 ? 1 : 0); }
-constexpr int BIAS_MAX = 480;                         // output channels per member the LDS bias table holds (5 blocks of 96)
 constexpr int EPI_PITCH = TT_COUT + 4;              // floats per staged pixel row
 constexpr int EPI_GROUPS = TT_COUT / 8, EPI_ITEMS = 32 * EPI_GROUPS, EPI_ITERS = EPI_ITEMS / 64;   // 12, 384, 6
 static_assert(wp_first(4) == NKS * MI && 32 * EPI_PITCH * 4 <= 13 * 1024, "a wave's epilogue staging must fit its own block of the weight region");
 }  // namespace
 
+// member m's parameters straight from the kernel-argument segment, by scalar loads at a computed offset (selecting among three
+// by-value copies of the argument keeps ~80 SGPRs alive and spills; a dynamically indexed argument is copied to scratch)
+__device__ __forceinline__ TTMember load_member(int m) {
+    TTMember r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(TTMember) % 4 == 0 && offsetof(TTParams, m) == 0, "the members must open the kernel-argument segment");
+    const __attribute__((address_space(4))) unsigned* src =
+        (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr() + m * (int)(sizeof(TTMember) / 4);
+    unsigned* dst = reinterpret_cast<unsigned*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(TTMember) / 4; ++i) dst[i] = src[i];
+#else
+    (void)m;
+    r = TTMember{};
+#endif
+    return r;
+}
+
+// FP8 = false: bf16 operands, v_mfma_f32_32x32x16_bf16, stages of 32 input channels.
+// FP8 = true (BASELINE config C5): OCP e4m3 operands -- the input is the e4m3 twin of the activation tensor (per-tensor scale),
+// the weights carry one scale per output channel -- on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: stages of 64
+// input channels in the same 54 KB + 22.5 KB of LDS, i.e. half the stages and half the DMA bytes per MAC, twice the MACs per
+// matrix-pipe cycle.  y = sum * (input scale x weight scale) + folded-BN shift is applied in the epilogue; the output goes out
+// as bf16 and / or as the e4m3 twin the next fp8 convolution reads.
+template <bool FP8>
 __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -69,7 +96,9 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     const unsigned T = blockIdx.x * 2u + (unsigned)team;
     char* const s_w = smem + team * TEAM_BYTES;
     char* const s_h = s_w + W_BYTES;
-    float* const s_bias = reinterpret_cast<float*>(smem + 2 * TEAM_BYTES + 64);     // [3 members][BIAS_MAX] folded-BN shifts
+    float* const s_bias = reinterpret_cast<float*>(smem + 2 * TEAM_BYTES + 64);     // folded-BN shifts of the members, back to back
+    float* const s_osc = s_bias + TT_TABLE_MAX;                                     // fp8 variant: output scales, same indexing
+    const int tab1 = P.m[0].cout, tab2 = P.m[0].cout + P.m[1].cout;                 // table offsets of members 1 and 2
 
     unsigned it = P.team_first[T];
     const unsigned SA = P.team_stages[blockIdx.x * 2u], SB = P.team_stages[blockIdx.x * 2u + 1u];
@@ -83,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            bptr[dx][k] = s_h + ((tw * 2 * HP + l31 + dx) * 64 + ((tw * 2 + ((l31 + dx) >> 2) + hi + k) & 3) * 16);
+            bptr[dx][k] = s_h + ((tw * 2 * HP + l31 + dx) * 64 + ((tw * 2 + ((l31 + dx) >> 2) + (FP8 ? 2 * hi : hi) + k) & 3) * 16);
     const char* const aptr = s_w + lane * 16;
 
     unsigned long long* const trc = P.trace ? P.trace + (size_t)T * 256 : nullptr;
@@ -99,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     // channel block: SALU) and per-lane constants.
     f32x16 acc[MB][NB];
     unsigned hv[6];                       // per-lane byte offsets of this wave's halo DMA pieces (stage-independent)
-    TTMember M = P.m[0];
-    int nb = 0, c = 0, row0 = 0, col0 = 0;
+    TTMember M = load_member(0);
+    int nb = 0, c = 0, row0 = 0, col0 = 0, tab = 0;
 
     // byte offset of this lane's 16 bytes of halo piece `piece`: slot q of the [pixel][4] image holds channel group
     // (q & 3) - (pixel >> 2) mod 4; pitch padding, rows / columns outside the frame and the shared zero row between
@@ -117,13 +146,11 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         const int y = s - (int)f * (M.H + 1);
         const int x = col0 - 1 + (int)hcol;
         const bool ok = (hrow < (unsigned)HROWS) & (hcol < 34u) & (s >= 0) & ((int)f < M.N) & (y < M.H) & ((unsigned)x < (unsigned)M.W);
-        return ok ? (unsigned)((((int)f * M.H + y) * M.W + x) * M.Cin * 2) + cg * 16u : 0x80000000u;
+        return ok ? (unsigned)((((int)f * M.H + y) * M.W + x) * M.Cin * (FP8 ? 1 : 2)) + cg * 16u : 0x80000000u;
     };
 
     auto setup_item = [&](const TTItem I) {
-        M = P.m[0];
-        if (I.member == 1) M = P.m[1];
-        if (I.member == 2) M = P.m[2];
+        M = load_member(I.member);
         nb = I.nb; row0 = I.row0; col0 = I.col0;
         int lane_l = lane;                 // laundered: hipcc would hoist the lane-only parts out of the stage loop and spill them
         asm volatile("" : "+v"(lane_l));
@@ -133,17 +160,27 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         // accumulators start at the folded-BN shift: register quad q of block mb holds channels mb * 32 + 8 q + 4 hi + 0..3 of
         // pixel l31.  The shifts come from a table in LDS (filled once per workgroup): a global load here would sit behind the
         // old tile's stores and its wait, vmcnt(0), would last until every store has drained
-        const float* const bt = s_bias + I.member * BIAS_MAX + nb * TT_COUT + 4 * hi;
+        tab = I.member == 0 ? 0 : I.member == 1 ? tab1 : tab2;
+        if constexpr (FP8) {               // fp8: plain sums; scale and shift are applied in the epilogue
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bs = *reinterpret_cast<const float4*>(bt + mb * 32 + 8 * q);
+                for (int jr = 0; jr < NB; ++jr)
 #pragma unroll
-                for (int jr = 0; jr < NB; ++jr) {
-                    acc[mb][jr][4 * q + 0] = bs.x; acc[mb][jr][4 * q + 1] = bs.y; acc[mb][jr][4 * q + 2] = bs.z; acc[mb][jr][4 * q + 3] = bs.w;
+                    for (int r = 0; r < 16; ++r) acc[mb][jr][r] = 0.f;
+        } else {
+            const float* const bt = s_bias + tab + nb * TT_COUT + 4 * hi;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bs = *reinterpret_cast<const float4*>(bt + mb * 32 + 8 * q);
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr) {
+                        acc[mb][jr][4 * q + 0] = bs.x; acc[mb][jr][4 * q + 1] = bs.y; acc[mb][jr][4 * q + 2] = bs.z; acc[mb][jr][4 * q + 3] = bs.w;
+                    }
                 }
-            }
+        }
     };
 
     auto setup_done_stamp = [&]() { if (eix > 192) estamp(); };
@@ -168,9 +205,12 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     // it before the next -- twelve dependent HBM round trips, 12k clk per tile against a 4k clk MFMA phase of the other team.)
     auto epilogue = [&]() {
         const unsigned out_bytes = (unsigned)(M.N * M.H * M.W * M.out_cstride * 2);
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.res ? M.res : M.out), 0,
+        const __amdgpu_buffer_rsrc_t rs_out8 = __builtin_amdgcn_make_buffer_rsrc(FP8 && M.out8 ? M.out8 : const_cast<void*>(M.in), 0,
+                                                                                   FP8 && M.out8 ? (int)(out_bytes / 2) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.res ? M.res : M.in), 0,
                                                                                   M.res ? (int)out_bytes : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(M.out, 0, (int)out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(M.out ? M.out : const_cast<void*>(M.in), 0,
+                                                                                  M.out ? (int)out_bytes : 0, 0x00020000);     // no bf16 output: zero-sized
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const bool has_res = M.res != nullptr;      // the first conv of a BasicBlock has none: no loads, no unpack / add (a VALU
         estamp();                                   // instruction beside a multiplying partner costs ~8 clk, a load ~160)
@@ -220,6 +260,15 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                 const float* sp = stg + (lane_off[e] >> 1) - px_e[e] * (M.out_cstride - EPI_PITCH);     // px * PITCH + grp * 8
                 const float4 lo = *reinterpret_cast<const float4*>(sp), hi4 = *reinterpret_cast<const float4*>(sp + 4);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if constexpr (FP8) {             // y = sum * (input scale x weight scale of the channel) + folded-BN shift
+                    __builtin_amdgcn_sched_barrier(0);       // (hipcc hoists the table reads of all twelve items otherwise: 190 registers)
+                    const int ch = tab + nb * TT_COUT + (int)(lane_off[e] >> 1) - px_e[e] * M.out_cstride;      // ... + grp * 8
+                    const float4 s0 = *reinterpret_cast<const float4*>(s_osc + ch), s1 = *reinterpret_cast<const float4*>(s_osc + ch + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(s_bias + ch), b1 = *reinterpret_cast<const float4*>(s_bias + ch + 4);
+                    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bi[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + bi[k];
+                }
                 if (has_res) {
                     const bf16x8 r = __builtin_bit_cast(bf16x8, rr[jr][e]);
 #pragma unroll
@@ -234,44 +283,101 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     q = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), z));
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs_out, voff[jr][e], soff[jr], 0);
+                if constexpr (FP8) {             // e4m3 twin for the next fp8 convolution: the ROUNDED bf16 value / scale, saturated
+                    float w8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) w8[k] = fminf(fmaxf((float)q[k] * M.out8_inv_scale, -448.f), 448.f);
+                    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], 0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], p0, true);
+                    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], 0, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], p1, true);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const unsigned v8 = voff[jr][e] == 0x80000000u ? 0x80000000u : voff[jr][e] >> 1;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)p0, (unsigned)p1}, rs_out8, v8, soff[jr] >> 1, 0);
+                }
             }
         }
         estamp();
     };
 
-    // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t multiplies.
-    // `near_end` runs before the last two steps (the token is handed on while ~400 clk of MFMAs are still queued).
     auto multiply_stage = [&](auto&& near_end) {
-        bf16x8 a[2][MB], b[2][NB];
-        auto load_frags = [&](int t, int buf) {
-            const int s = t >> 1, h = t & 1, dy = s / 3, dx = s - dy * 3;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[buf][mb] = *reinterpret_cast<const bf16x8*>(aptr + (t * MB + mb) * 1024);
-#pragma unroll
-            for (int jr = 0; jr < NB; ++jr)
-                b[buf][jr] = *reinterpret_cast<const bf16x8*>(bptr[dx][(jr + dy + 2 * h) & 3] + (jr + dy) * HP * 64);
-        };
         // pin the accumulators where they are: without this hipcc copies the 96 registers on entry (two reaching
-        // definitions: the bias of a new item / the previous stage) and spills some of the originals around the phase
+        // definitions: the start value of a new item / the previous stage) and spills some of the originals around the phase
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int jr = 0; jr < NB; ++jr) asm volatile("" : "+v"(acc[mb][jr]));
-        load_frags(0, 0);
+        if constexpr (FP8) {
+            // fp8 stage = 64 input channels: 9 K = 64 steps (one per tap) x 6 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+            // scales (E8M0 127).  Lane l holds 32 consecutive K bytes of row / column l & 31: channels 32 (l >> 5) .. + 31 of
+            // the tap = two 16-byte slots of the pixel, two lane-linear 1 KB pieces of the weights (layout probed on hardware:
+            // tools/dev/mx_probe.hip).
+            i32x8 a[2][MB], b[2][NB];
+            auto load_frags = [&](int s, int buf) {
+                const int dy = s / 3, dx = s - dy * 3;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int cur = t & 1;
-            if (t == NT - 2) near_end();
-            if (t + 1 < NT) {
-                load_frags(t + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);                 // ... and keep the reads ABOVE this step's MFMAs: hipcc otherwise sinks
-            }                                                      // them below five of the six (register reuse) and every step waits for LDS
+                for (int mb = 0; mb < MB; ++mb) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(aptr + ((s * MB + mb) * 2 + 0) * 1024);
+                    const i32x4 hi4 = *reinterpret_cast<const i32x4*>(aptr + ((s * MB + mb) * 2 + 1) * 1024);
+                    a[buf][mb] = i32x8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int jr = 0; jr < NB; ++jr) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(bptr[dx][(jr + dy) & 3] + (jr + dy) * HP * 64);
+                    const i32x4 hi4 = *reinterpret_cast<const i32x4*>(bptr[dx][(jr + dy + 1) & 3] + (jr + dy) * HP * 64);
+                    b[buf][jr] = i32x8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int t = 0; t < NKS; ++t) {
+                const int cur = t & 1;
+                if (t + 1 < NKS) {
+                    load_frags(t + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr)
+                        acc[mb][jr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[cur][mb], b[cur][jr], acc[mb][jr], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                // anchor the step: hipcc sinks the scaled MFMAs of ALL steps below the last reads otherwise (sched_barrier does
+                // not hold them), keeps nine steps of fragments alive and spills ~290 registers
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr) asm volatile("" : "+v"(acc[mb][jr]) :: "memory");
+                if (t + 1 < NKS) __builtin_amdgcn_sched_barrier(0);
+            }
+            near_end();
+        } else {
+            // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t
+            // multiplies.  `near_end` runs before the last two steps (the token is handed on while ~400 clk of MFMAs are queued).
+            bf16x8 a[2][MB], b[2][NB];
+            auto load_frags = [&](int t, int buf) {
+                const int s = t >> 1, h = t & 1, dy = s / 3, dx = s - dy * 3;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a[buf][mb] = *reinterpret_cast<const bf16x8*>(aptr + (t * MB + mb) * 1024);
 #pragma unroll
                 for (int jr = 0; jr < NB; ++jr)
-                    acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mb], b[cur][jr], acc[mb][jr], 0, 0, 0);
-            if (t + 1 < NT) __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the next step's MFMAs
+                    b[buf][jr] = *reinterpret_cast<const bf16x8*>(bptr[dx][(jr + dy + 2 * h) & 3] + (jr + dy) * HP * 64);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int cur = t & 1;
+                if (t == NT - 2) near_end();
+                if (t + 1 < NT) {
+                    load_frags(t + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);             // ... and keep the reads ABOVE this step's MFMAs: hipcc otherwise sinks
+                }                                                  // them below five of the six (register reuse) and every step waits for LDS
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr)
+                        acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mb], b[cur][jr], acc[mb][jr], 0, 0, 0);
+                if (t + 1 < NT) __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the next step's MFMAs
+            }
         }
     };
 
@@ -294,8 +400,13 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     unsigned* const w_early = w_arrive + 3;
     if (tid < 16) ctrl[tid] = 0u;
 #pragma unroll
-    for (int m = 0; m < TT_MAX_MEMBERS; ++m)
-        if (P.m[m].bias && tid < P.m[m].cout) s_bias[m * BIAS_MAX + tid] = P.m[m].bias[tid];
+    for (int m = 0; m < TT_MAX_MEMBERS; ++m) {
+        const int o = m == 0 ? 0 : m == 1 ? tab1 : tab2;
+        if (P.m[m].bias && tid < P.m[m].cout) {
+            s_bias[o + tid] = P.m[m].bias[tid];
+            if constexpr (FP8) s_osc[o + tid] = P.m[m].oscale[tid];
+        }
+    }
     __syncthreads();
     auto poll = [&](unsigned* p) -> unsigned { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto spin_until = [&](unsigned* p, unsigned target) {
@@ -351,13 +462,16 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     if (S > 0) { epilogue(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 }
 
-void launch_conv_tt(const TTParams& p, int n_wgs, hipStream_t s) {
+void launch_conv_tt(const TTParams& p, int n_wgs, bool fp8, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    SNCAL_LAUNCH(conv_tt_kernel, dim3((unsigned)n_wgs), dim3(512), (size_t)2 * TEAM_BYTES + 64 + TT_MAX_MEMBERS * BIAS_MAX * 4, s, p);
+    const size_t lds = (size_t)2 * TEAM_BYTES + 64 + 2 * TT_TABLE_MAX * 4;
+    if (fp8) SNCAL_LAUNCH(conv_tt_kernel<true>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
+    else SNCAL_LAUNCH(conv_tt_kernel<false>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
 }
 
 }  // namespace sncal

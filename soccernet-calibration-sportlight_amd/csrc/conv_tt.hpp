@@ -12,8 +12,8 @@ constexpr int TT_COUT = 96;         // output channels per work item (MI = 6 fra
 constexpr int TT_CIN = 32;          // input channels per stage (G = 4 k-groups of 8 bf16)
 
 struct TTMember {                   // one convolution of the launch: 3x3, stride 1, pad 1, bf16 NHWC, folded BN (+res)(+ReLU)
-    const void* in;                 // [N][H][W][Cin]
-    void* out;                      // [N][H][W][out_cstride], channels at out_coff
+    const void* in;                 // [N][H][W][Cin] bf16 (fp8 variant: the e4m3 twin of the tensor, 1 byte per element)
+    void* out;                      // [N][H][W][out_cstride] bf16, channels at out_coff (fp8 variant: may be NULL)
     const void* res;                // optional residual, indexed like out
     const void* w;                  // packed weights of the generic conv kernel for (MI = 6, G = 4): [nblk][chunk][9][6][64] x 16 B
     const float* bias;              // folded-BN shift, padded to nblk * 96
@@ -21,6 +21,10 @@ struct TTMember {                   // one convolution of the launch: 3x3, strid
     int cout, out_cstride, out_coff, relu;
     unsigned w_bytes, in_bytes;     // buffer-descriptor ranges
     unsigned hp1_magic;             // floor(2^32 / (H + 1)) + 1
+    // fp8 variant only (conv_tt_kernel<true>): y = acc * oscale[c] + bias[c] with oscale = input scale x weight scale of channel c
+    const float* oscale;            // [cout]
+    void* out8;                     // optional e4m3 twin of the output, indexed like out at 1 byte per element
+    float out8_inv_scale;           // 1 / (per-tensor scale of the output twin)
 };
 
 struct TTItem {                     // one output tile x one 96-channel block
@@ -38,6 +42,7 @@ struct TTParams {
     unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null
 };
 
-void launch_conv_tt(const TTParams& p, int n_wgs, hipStream_t s);
+void launch_conv_tt(const TTParams& p, int n_wgs, bool fp8, hipStream_t s);
+constexpr int TT_TABLE_MAX = 760;       // sum of the members' output channels the LDS bias / scale tables hold
 
 }  // namespace sncal

@@ -44,6 +44,13 @@ struct ConvLayer {
     void* d_w = nullptr;
     float* d_bias = nullptr;
     void* d_w_tt = nullptr;     // second packing, for the two-team kernel (conv_tt.hip): 32 x 32 x 16 MFMA fragment order
+    // C5 path: e4m3 weights of the same layer for conv_tt_kernel<true> (one scale per output channel), the scales, and
+    // oscale = (calibrated scale of the layer's input tensor) x (weight scale of the channel)
+    void* d_w8 = nullptr;
+    std::vector<float> wscale;
+    float* d_oscale = nullptr;
+    int stage = 0;              // 2..4 for model.stageN.* layers, 0 otherwise
+    bool fp8_on = false;
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
@@ -71,6 +78,9 @@ struct Tensor {
     int C = 0;
     bool f32 = false;         // fp32 storage regardless of the net dtype (logits / heat)
     bool external_heat = false;
+    bool fp8 = false;            // e4m3 twin (1 byte per element) of a bf16 tensor, input of an fp8 convolution
+    int twin = -1;               // index of this tensor's fp8 twin, if any
+    float scale = 0.f;           // calibrated per-tensor scale of the twin: amax / 448
     int first = -1, last = -1;   // producing / last consuming op
     // per-run
     int H = 0, W = 0;
@@ -102,6 +112,13 @@ struct sncal_hrnet {
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
+    // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
+    bool fp8 = false, fp8_calibrated = false, calibrating = false;
+    unsigned fp8_stages = 0;                  // bit s: stage s selected (0 = all stages)
+    std::vector<int> fp8_widths;              // selected channel widths (empty = all)
+    unsigned* d_amax = nullptr;               // calibration: per-tensor max |x| (float bit patterns)
+    std::vector<char> need_bf16;              // per tensor: some active consumer reads the bf16 tensor
+    std::vector<int> producer;                // per tensor: active op that writes it
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
@@ -144,6 +161,7 @@ struct Builder {
     int add_layer(const std::string& name, const std::string& bn, int cin, int cout, int k, int stride, bool bias) {
         ConvLayer L;
         L.name = name; L.bn = bn; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.bias = bias;
+        { const size_t q = name.find("stage"); if (q != std::string::npos && q + 5 < name.size()) L.stage = name[q + 5] - '0'; }
         net.layers.push_back(L);
         net.layer_by_name[name] = (int)net.layers.size() - 1;
         return (int)net.layers.size() - 1;
@@ -390,6 +408,18 @@ struct Builder {
         { Op op; op.type = OP_SOFTMAX; op.in = logits; op.out = new_tensor(d.num_classes, true);
           net.tensors[op.out].external_heat = true; net.t_heat = op.out; net.ops.push_back(op); }
         { Op op; op.type = OP_DECODE; op.in = net.t_heat; net.ops.push_back(op); }
+        // C5: every wide 3x3 stride-1 convolution may run in fp8 -> its input tensor gets an e4m3 twin (allocated only while
+        // the layer is selected, see layout())
+        if (net.fp8)
+            for (const Op& op : net.ops) {
+                if (op.type != OP_CONV) continue;
+                const ConvLayer& L = net.layers[op.conv];
+                if (L.k == 3 && L.stride == 1 && L.cin % 32 == 0 && L.cout % TT_COUT == 0 && net.tensors[op.in].C == L.cin && net.tensors[op.in].twin < 0) {
+                    const int tw = new_tensor(L.cin);
+                    net.tensors[tw].fp8 = true;
+                    net.tensors[op.in].twin = tw;
+                }
+            }
         // lifetimes
         for (size_t i = 0; i < net.ops.size(); ++i) {
             const Op& op = net.ops[i];
@@ -512,6 +542,63 @@ int pack_layer_tt(sncal_hrnet& net, ConvLayer& L) {
     return SNCAL_OK;
 }
 
+// float -> OCP e4m3fn (1-4-3, bias 7, max 448, no infinities), round to nearest even, saturating
+inline uint8_t f2fp8(float f) {
+    if (!(f == f)) return 0x7f;
+    const uint8_t sign = f < 0 ? 0x80 : 0;
+    float a = std::fabs(f);
+    if (a >= 448.f) return sign | 0x7e;
+    if (a < 0.0009765625f) return sign;                    // below half the smallest subnormal (2^-9 / 2): zero
+    int e;
+    float m = std::frexp(a, &e);                            // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1 + 7;                                      // biased exponent of 1.xxx * 2^(e-1)
+    int q;
+    if (E >= 1) {                                           // normal: 3 mantissa bits
+        const float x = (m * 2.f - 1.f) * 8.f;
+        q = (int)std::nearbyint(x);
+        if (q == 8) { q = 0; ++E; }
+        if (E > 15 || (E == 15 && q > 6)) return sign | 0x7e;
+        return sign | (uint8_t)(E << 3) | (uint8_t)q;
+    }
+    q = (int)std::nearbyint(a * 512.f);                     // subnormal: multiples of 2^-9
+    if (q >= 8) return sign | 0x08;
+    return sign | (uint8_t)q;
+}
+
+// Packing of a wide 3x3 stride-1 layer for the fp8 variant of the two-team kernel: per (96-channel block nb, 64-channel chunk c)
+// one 54 KB stage [tap 9][32-row block 3][half 2][lane 64] x 16 e4m3, the A operand of v_mfma_scale_f32_32x32x64_f8f6f4: lane l
+// holds output channel nb * 96 + mb * 32 + (l & 31), input channels c * 64 + 32 (l >> 5) + 16 half + 0..15 of the tap (zeros
+// beyond Cin).  One scale per output channel: wscale = max |w| / 448 over the folded weights of the channel.
+int pack_layer_fp8(sncal_hrnet& net, ConvLayer& L) {
+    if (L.d_w8) { (void)hipFree(L.d_w8); L.d_w8 = nullptr; }
+    if (!net.fp8 || !tt_shape_ok(net, L)) return SNCAL_OK;
+    const int chunks = (L.cin + 63) / 64, nblk = L.cout / TT_COUT;
+    L.wscale.assign(L.cout, 1.f);
+    for (int co = 0; co < L.cout; ++co) {
+        float mx = 0.f;
+        for (size_t i = 0; i < (size_t)L.cin * 9; ++i) mx = std::max(mx, std::fabs(L.w[(size_t)co * L.cin * 9 + i] * L.scale[co]));
+        L.wscale[co] = mx > 0.f ? mx / 448.f : 1.f;
+    }
+    std::vector<uint8_t> host((size_t)nblk * chunks * 9 * 3 * 2 * 64 * 16, 0);
+    for (int nb = 0; nb < nblk; ++nb)
+        for (int c = 0; c < chunks; ++c)
+            for (int s = 0; s < 9; ++s)
+                for (int mb = 0; mb < 3; ++mb)
+                    for (int half = 0; half < 2; ++half)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = nb * TT_COUT + mb * 32 + (lane & 31);
+                            uint8_t* dst = host.data() + (((((((size_t)nb * chunks + c) * 9 + s) * 3 + mb) * 2 + half) * 64) + lane) * 16;
+                            for (int e = 0; e < 16; ++e) {
+                                const int ci = c * 64 + 32 * (lane >> 5) + 16 * half + e;
+                                if (ci < L.cin) dst[e] = f2fp8(L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co] / L.wscale[co]);
+                            }
+                        }
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w8, host.size()));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w8, host.data(), host.size(), hipMemcpyHostToDevice));
+    if (!L.d_oscale) SNCAL_CHECK_HIP(hipMalloc((void**)&L.d_oscale, (size_t)L.cout * 4));
+    return SNCAL_OK;
+}
+
 // stage-1 / stage-2 A fragments + biases of the fused head (head.hip), bf16 only
 int pack_head(sncal_hrnet& net) {
     if (net.dtype != SNCAL_BF16) return SNCAL_OK;
@@ -579,6 +666,12 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         const bool dims_ok = net.desc.upscale == 1 || (sh == bh * net.desc.upscale && sw == bw * net.desc.upscale);
         net.use_fused = net.fused_enabled && net.dtype == SNCAL_BF16 && dims_ok && net.d_hw0 != nullptr;
     }
+    for (ConvLayer& L : net.layers) {       // C5: which layers run in fp8 (selection set by sncal_hrnet_set_fp8_layers)
+        bool w_ok = net.fp8_widths.empty();
+        for (int w : net.fp8_widths) w_ok = w_ok || w == L.cout;
+        const bool s_ok = net.fp8_stages == 0 || ((net.fp8_stages >> L.stage) & 1u);
+        L.fp8_on = net.fp8 && net.fp8_calibrated && !net.calibrating && L.d_w8 != nullptr && w_ok && s_ok && L.stage >= 2;
+    }
     for (Tensor& t : T) { t.first = -1; t.last = -1; }
     for (size_t i = 0; i < net.ops.size(); ++i) {       // lifetimes over the active ops
         const Op& op = net.ops[i];
@@ -603,6 +696,31 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         }
         for (Tensor& t : T) { if (t.first >= 0) t.first = gfirst[t.first]; if (t.last >= 0) t.last = glast[t.last]; }
     }
+    {   // C5: an e4m3 twin lives exactly as long as its bf16 tensor, and only while an fp8 convolution reads it;
+        // who writes each tensor, and whether anybody still reads the bf16 version (residuals, fuse layers, bf16 convs)
+        net.producer.assign(T.size(), -1);
+        net.need_bf16.assign(T.size(), 0);
+        std::vector<char> twin_used(T.size(), 0);
+        for (size_t i = 0; i < net.ops.size(); ++i) {
+            const Op& op = net.ops[i];
+            if (!op_active(net, op)) continue;
+            if (op.out >= 0 && net.producer[op.out] < 0) net.producer[op.out] = (int)i;
+            auto bf = [&](int t) { if (t >= 0) net.need_bf16[t] = 1; };
+            bf(op.res); bf(op.base); bf(op.dims_from); bf(op.head_direct);
+            for (int k = 0; k < op.nsrc; ++k) bf(op.srcs[k]);
+            for (int k = 0; k < op.head_nsrc; ++k) bf(op.head_src[k]);
+            for (int k = 0; k < op.head_nfold; ++k) bf(op.head_fold[k]);
+            if (op.in >= 0) {
+                const bool f8 = op.type == OP_CONV && net.layers[op.conv].fp8_on && T[op.in].twin >= 0;
+                if (f8) twin_used[op.in] = 1; else bf(op.in);
+            }
+        }
+        for (size_t t = 0; t < T.size(); ++t)
+            if (T[t].twin >= 0) {
+                Tensor& w = T[T[t].twin];
+                if (twin_used[t]) { w.first = T[t].first; w.last = T[t].last; } else { w.first = w.last = -1; }
+            }
+    }
     for (const Op& op : net.ops) {
         if (!op_active(net, op)) continue;
         switch (op.type) {
@@ -623,6 +741,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
             case OP_DECODE: break;
         }
     }
+    for (Tensor& t : T) if (t.twin >= 0) { T[t.twin].H = t.H; T[t.twin].W = t.W; }
     // first-fit allocator over op order
     struct Blk { size_t off, size; };
     std::vector<Blk> free_list;
@@ -650,7 +769,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
     for (size_t i = 0; i < net.ops.size(); ++i) {
         for (size_t t = 0; t < T.size(); ++t)
             if (T[t].first == (int)i) {
-                T[t].bytes = (size_t)sb * T[t].H * T[t].W * T[t].C * (T[t].f32 ? 4 : net.esize);
+                T[t].bytes = (size_t)sb * T[t].H * T[t].W * T[t].C * (T[t].f32 ? 4 : T[t].fp8 ? 1 : net.esize);
                 T[t].offset = alloc(T[t].bytes);
             }
         for (size_t t = 0; t < T.size(); ++t)
@@ -771,6 +890,16 @@ bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb) {
     return in_bytes < (1u << 31) && out_elems < (1ull << 32) && (size_t)L.nblk * L.chunks * 9 * 6 * 1024 < (1u << 31);
 }
 
+// does the active op that produced tensor t write its e4m3 twin itself (an fp8 convolution on the two-team kernel)?
+bool twin_written_by_producer(const sncal_hrnet& net, int t, int sb) {
+    static const bool no_twin_out = getenv("SNCAL_FP8_NO_TWIN_OUT") != nullptr;      // debugging aid: every twin through the quantise kernel
+    if (no_twin_out) return false;
+    const int pi = t >= 0 && t < (int)net.producer.size() ? net.producer[t] : -1;
+    if (pi < 0) return false;
+    const Op& po = net.ops[pi];
+    return po.type == OP_CONV && net.layers[po.conv].fp8_on && tt_eligible(net, po, sb);
+}
+
 void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember& m) {
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
@@ -783,6 +912,19 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
     m.w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * m.chunks * 9 * 6 * 1024);
     m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C * 2);
     m.hp1_magic = 0xFFFFFFFFu / (unsigned)(ti.H + 1) + 1u;
+    if (L.fp8_on) {          // C5: e4m3 twin in, 64-channel stages, e4m3 weights; outputs: bf16 if anybody reads it, twin if an fp8 conv follows
+        m.in = ws + net.tensors[ti.twin].offset;
+        m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C);
+        m.chunks = (L.cin + 63) / 64;
+        m.w = L.d_w8;
+        m.w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * m.chunks * 9 * 6 * 1024);
+        m.oscale = L.d_oscale;
+        const bool twin_out = to.twin >= 0 && net.tensors[to.twin].first >= 0;
+        m.out8 = twin_out ? ws + net.tensors[to.twin].offset : nullptr;
+        m.out8_inv_scale = twin_out && to.scale > 0.f ? 1.0f / to.scale : 1.0f;
+        if (!net.need_bf16[op.out]) m.out = nullptr;
+        if (getenv("SNCAL_FP8_NO_TWIN_OUT")) { m.out8 = nullptr; m.out = ws + to.offset; }
+    }
 }
 
 // Deal the work items of the member convolutions to the 2 * n_wgs teams.  Workgroup b runs on XCD b % 8 (observed
@@ -844,11 +986,25 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     return SNCAL_OK;
 }
 
-// the ops [ops, ops + n) (independent, all eligible) as ONE launch of the two-team kernel
+// the ops [ops, ops + n) (independent, all eligible, all bf16 or all fp8) as ONE launch of the two-team kernel
 int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* ws, hipStream_t stream) {
     TTParams tp;
     memset(&tp, 0, sizeof(tp));
-    for (int i = 0; i < n; ++i) tt_member(net, ops[i], sb, ws, tp.m[i]);
+    const bool fp8 = net.layers[ops[0].conv].fp8_on;
+    for (int i = 0; i < n; ++i) {
+        if (net.calibrating && net.tensors[ops[i].in].twin >= 0) {        // C5 calibration: max |x| of every candidate input tensor
+            const Tensor& ti = net.tensors[ops[i].in];
+            const int rc = launch_absmax_bf16(ws + ti.offset, (size_t)sb * ti.H * ti.W * ti.C, net.d_amax + ops[i].in, stream);
+            if (rc) return rc;
+        }
+        if (fp8 && !twin_written_by_producer(net, ops[i].in, sb)) {      // first fp8 conv of a chain: quantise its input here
+            const Tensor& ti = net.tensors[ops[i].in];
+            const int rc = launch_quantize_fp8(ws + ti.offset, ws + net.tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, ti.scale, stream);
+            if (rc) return rc;
+        }
+        tt_member(net, ops[i], sb, ws, tp.m[i]);
+    }
+    if (fp8) key += 1 << 30;                                               // fp8 plans have their own stage counts
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
@@ -862,7 +1018,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     unsigned long long* d_trace = nullptr;
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
     if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
-    launch_conv_tt(tp, it->second.n_wgs, stream);
+    launch_conv_tt(tp, it->second.n_wgs, fp8, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -871,9 +1027,26 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         (void)hipFree(d_trace);
         if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_trace, f); fclose(f); }
     }
+    static const bool fp8_debug = getenv("SNCAL_FP8_DEBUG") != nullptr;      // tuning aid: range of every fp8 launch's bf16 outputs
+    if (fp8 && fp8_debug) {
+        (void)hipStreamSynchronize(stream);
+        for (int i = 0; i < n; ++i) {
+            const Tensor& to = net.tensors[ops[i].out];
+            const Tensor& ti = net.tensors[ops[i].in];
+            const size_t ne = (size_t)sb * to.H * to.W * to.C;
+            std::vector<uint16_t> h(ne);
+            double mx = 0, sum = 0; size_t bad = 0;
+            if (tp.m[i].out) {
+                (void)hipMemcpy(h.data(), tp.m[i].out, ne * 2, hipMemcpyDeviceToHost);
+                for (size_t k = 0; k < ne; ++k) { uint32_t u = (uint32_t)h[k] << 16; float f; memcpy(&f, &u, 4); if (!(std::fabs(f) < 1e3f)) { if (bad < 48) fprintf(stderr, "   bad %g at n %zu y %zu x %zu c %zu\n", f, k / ((size_t)to.H * to.W * to.C), (k / ((size_t)to.W * to.C)) % to.H, (k / to.C) % to.W, k % to.C); ++bad; } else { mx = std::max(mx, (double)std::fabs(f)); sum += std::fabs(f); } }
+            }
+            fprintf(stderr, "[fp8] %-44s in_scale %.4g out_scale %.4g bf16_out %d twin_out %d  |out| max %.4g mean %.4g bad %zu\n", net.layers[ops[i].conv].name.c_str(),
+                    ti.scale, to.scale, tp.m[i].out != nullptr, tp.m[i].out8 != nullptr, mx, ne ? sum / ne : 0.0, bad);
+        }
+    }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
     }
     return SNCAL_OK;
 }
@@ -913,8 +1086,12 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
     if (n < 2 || n > 3) return SNCAL_OK;
     {
         bool all_tt = true;
-        for (int i = 0; i < n; ++i) all_tt = all_tt && tt_eligible(net, ops[i], sb);
-        if (all_tt) {
+        int couts = 0;
+        for (int i = 0; i < n; ++i) {
+            all_tt = all_tt && tt_eligible(net, ops[i], sb) && net.layers[ops[i].conv].fp8_on == net.layers[ops[0].conv].fp8_on;
+            couts += net.layers[ops[i].conv].cout;
+        }
+        if (all_tt && couts <= TT_TABLE_MAX) {
             const int rc = run_conv_tt(net, ops, n, (int)(ops - net.ops.data()) * 4096 + sb, sb, ws, stream);
             *done = rc == SNCAL_OK;
             return rc;
@@ -956,7 +1133,7 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
 
 extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out) {
     SNCAL_CHECK_ARG(desc && out, "sncal_hrnet_create: null pointer");
-    SNCAL_CHECK_ARG(dtype == SNCAL_F32 || dtype == SNCAL_BF16, "sncal_hrnet_create: dtype %d", dtype);
+    SNCAL_CHECK_ARG(dtype == SNCAL_F32 || dtype == SNCAL_BF16 || dtype == SNCAL_FP8, "sncal_hrnet_create: dtype %d", dtype);
     SNCAL_CHECK_ARG(desc->stem_width == 64, "stem_width must be 64 (layer1 input is hard-coded, hrnet.py:273)");
     SNCAL_CHECK_ARG(desc->num_classes >= 2 && desc->num_classes <= 64, "num_classes %d out of range", desc->num_classes);
     SNCAL_CHECK_ARG(desc->upscale == 1 || desc->upscale == 2, "upscale must be 1 or 2");
@@ -970,6 +1147,8 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
     SNCAL_CHECK_ARG(desc->stage1_blocks >= 1 && desc->stage1_channels % 16 == 0, "stage1 config");
     sncal_hrnet* net = new sncal_hrnet();
     net->desc = *desc;
+    net->fp8 = dtype == SNCAL_FP8;            // C5: the bf16 engine with e4m3 arithmetic in the wide 3x3 stride-1 convolutions
+    if (net->fp8) dtype = SNCAL_BF16;
     net->dtype = dtype;
     net->ge = dtype == SNCAL_BF16 ? 8 : 4;
     net->esize = dtype == SNCAL_BF16 ? 2 : 4;
@@ -985,8 +1164,9 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
+    if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
 }
@@ -1050,6 +1230,8 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         if (rc) return rc;
         rc = pack_layer_tt(*net, L);
         if (rc) return rc;
+        rc = pack_layer_fp8(*net, L);
+        if (rc) return rc;
         std::vector<float>().swap(L.w);
     }
     net->finalized = true;
@@ -1085,6 +1267,65 @@ hipEvent_t next_event(sncal_hrnet& net) {
     return net.event_pool[net.events_used++];
 }
 }  // namespace
+
+static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char* d_x8, int B, int H, int W, float* d_heat,
+                        float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_);
+
+extern "C" int sncal_hrnet_set_fp8_layers(sncal_hrnet* net, const char* spec) {
+    SNCAL_CHECK_ARG(net && spec, "sncal_hrnet_set_fp8_layers: null");
+    SNCAL_CHECK_ARG(net->fp8, "sncal_hrnet_set_fp8_layers: the network was not created with SNCAL_FP8");
+    unsigned stages = 0;
+    std::vector<int> widths;
+    bool none = false;
+    std::string tok;
+    const std::string sp = std::string(spec) + ",";
+    for (char ch : sp) {
+        if (ch != ',') { if (ch != ' ') tok += ch; continue; }
+        if (tok.empty()) continue;
+        if (tok == "all") { stages = 0; widths.clear(); }
+        else if (tok == "none") none = true;
+        else if (tok.size() == 6 && tok.compare(0, 5, "stage") == 0 && tok[5] >= '2' && tok[5] <= '4') stages |= 1u << (tok[5] - '0');
+        else if (tok.size() >= 2 && tok[0] == 'c' && atoi(tok.c_str() + 1) > 0) widths.push_back(atoi(tok.c_str() + 1));
+        else { set_error("sncal_hrnet_set_fp8_layers: token '%s' (use all, none, stage2..stage4, c<width>)", tok.c_str()); return SNCAL_ERR_ARG; }
+        tok.clear();
+    }
+    net->fp8_stages = none ? (1u << 31) : stages;       // bit 31 matches no stage: nothing selected
+    net->fp8_widths = widths;
+    net->lay_sb = -1;                                   // twins / lifetimes depend on the selection
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_calibrate_fp8(sncal_hrnet* net, const float* d_x, int B, int H, int W, void* d_ws, size_t ws_bytes, void* stream_) {
+    SNCAL_CHECK_ARG(net && d_x && d_ws, "sncal_hrnet_calibrate_fp8: null");
+    SNCAL_CHECK_ARG(net->fp8, "sncal_hrnet_calibrate_fp8: the network was not created with SNCAL_FP8");
+    hipStream_t stream = as_stream(stream_);
+    const size_t nt = net->tensors.size();
+    if (!net->d_amax) SNCAL_CHECK_HIP(hipMalloc((void**)&net->d_amax, nt * 4));
+    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_amax, 0, nt * 4, stream));
+    net->calibrating = true; net->lay_sb = -1;
+    // keypoints into the (unused) head of the workspace would alias activations: decode into a scratch buffer of our own
+    float* d_kp = nullptr;
+    SNCAL_CHECK_HIP(hipMalloc((void**)&d_kp, (size_t)B * (net->desc.num_classes - 1) * 3 * 4));
+    const int rc = forward_impl(net, d_x, nullptr, B, H, W, nullptr, d_kp, H, W, d_ws, ws_bytes, stream_);
+    net->calibrating = false; net->lay_sb = -1;
+    if (rc) { (void)hipFree(d_kp); return rc; }
+    std::vector<float> amax(nt);
+    SNCAL_CHECK_HIP(hipStreamSynchronize(stream));
+    SNCAL_CHECK_HIP(hipMemcpy(amax.data(), net->d_amax, nt * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_kp);
+    for (size_t t = 0; t < nt; ++t) net->tensors[t].scale = amax[t] > 0.f ? amax[t] / 448.f : 1.f;
+    // per-layer output scales: (scale of the layer's input tensor) x (weight scale of the channel)
+    for (const Op& op : net->ops) {
+        if (op.type != OP_CONV) continue;
+        ConvLayer& L = net->layers[op.conv];
+        if (!L.d_w8 || net->tensors[op.in].twin < 0) continue;
+        std::vector<float> os(L.cout);
+        for (int co = 0; co < L.cout; ++co) os[co] = net->tensors[op.in].scale * L.wscale[co];
+        SNCAL_CHECK_HIP(hipMemcpy(L.d_oscale, os.data(), os.size() * 4, hipMemcpyHostToDevice));
+    }
+    net->fp8_calibrated = true;
+    return SNCAL_OK;
+}
 
 extern "C" int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_set_profiling: null");
@@ -1125,9 +1366,6 @@ extern "C" int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out,
     return SNCAL_OK;
 }
 
-static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char* d_x8, int B, int H, int W, float* d_heat,
-                        float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_);
-
 extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
                                    int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     return forward_impl(net, d_x, nullptr, B, H, W, d_heat, d_kpts, img_h, img_w, d_ws, ws_bytes, stream_);
@@ -1142,6 +1380,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         float* d_kpts, int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_forward: null net");
     if (!net->finalized) { set_error("sncal_hrnet_forward: weights not finalized"); return SNCAL_ERR_STATE; }
+    if (net->fp8 && !net->fp8_calibrated && !net->calibrating) { set_error("sncal_hrnet_forward: fp8 network without calibration (sncal_hrnet_calibrate_fp8)"); return SNCAL_ERR_STATE; }
     SNCAL_CHECK_ARG(B >= 0 && H >= 32 && W >= 32, "sncal_hrnet_forward: bad shape B=%d H=%d W=%d", B, H, W);
     if (B == 0) return SNCAL_OK;
     SNCAL_CHECK_ARG((d_x || d_x8) && d_ws, "sncal_hrnet_forward: null input / workspace");

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <algorithm>
 
 namespace sncal {
 
@@ -29,5 +30,10 @@ int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_tot
 size_t logsoftmax_decode_scratch(int B, int C, int h, int w);
 int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int h, int w, int img_h, int img_w, float* scratch,
                              float* kpts, hipStream_t s);
+
+// fp8 activation helpers (quant.hip): per-tensor |x| maximum (atomicMax into *d_out, a float's bit pattern; zero it first) and
+// bf16 -> fp8 e4m3 quantisation x / scale saturated to +-448
+int launch_absmax_bf16(const void* x, size_t n, unsigned* d_out, hipStream_t s);
+int launch_quantize_fp8(const void* x, void* y, size_t n, float scale, hipStream_t s);
 
 }  // namespace sncal

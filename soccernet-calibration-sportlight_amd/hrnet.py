@@ -19,7 +19,7 @@ from . import _lib
 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs')
 BN_EPS = 1e-5
-DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2, 'e4m3': 2}
 
 
 def _plain(obj):
@@ -208,6 +208,24 @@ class HRNetHeatmap:
                           ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
                        'sncal_hrnet_forward')
         return heat, kpts
+
+    # ---- C5: fp8 arithmetic in the wide 3x3 convolutions (dtype='fp8') -------------------------------------------
+    def calibrate_fp8(self, x: torch.Tensor):
+        """One bf16 forward of x (B,3,H,W) fp32 that records the per-tensor activation ranges the fp8 convolutions scale by."""
+        _lib.require_device(x, torch.float32, 'x')
+        B, C, H, W = x.shape
+        with torch.cuda.device(x.device):
+            ws = self._workspace(B, H, W)
+            _lib.check(self._L.sncal_hrnet_calibrate_fp8(self._h, x.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                                         _lib.current_stream_ptr()), 'sncal_hrnet_calibrate_fp8')
+        self._ws = None            # the fp8 layout adds the e4m3 twins: re-query the workspace
+        return self
+
+    def set_fp8_layers(self, spec: str = 'all'):
+        """Which wide 3x3 convolutions run in fp8: 'all', 'none', or e.g. 'stage4', 'stage3,stage4', 'c384', 'stage4,c192,c384'."""
+        _lib.check(self._L.sncal_hrnet_set_fp8_layers(self._h, spec.encode()), 'sncal_hrnet_set_fp8_layers')
+        self._ws = None
+        return self
 
     def set_profiling(self, enable):
         """Per-launch HIP event timing (measurement only): False/0 off, True/1 every launch, 2 only the launches of

@@ -117,7 +117,9 @@ def peaked_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.
 def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: float = 1.0, min_visible: int = 8,
                    size=(540, 960)):
     """(frames (n,3,H,W) float32 in [0,1] -- uniform-noise background in [0.25, 0.75) with the keypoint stamps --, expect (n,57,3) float32
-    rows [x_px, y_px, visible] on the 2-px decode grid).  Cameras are re-drawn until `min_visible` keypoints show."""
+    rows [x_px, y_px, visible] in 960x540 units on the decode grid of an (H/2, W/2) heatmap -- 2 px at 960x540, 1 px at
+    1920x1080: HRNetPredictionTransform scales by size=[540,960] whatever the input size, transforms.py:234-235).
+    Cameras are re-drawn until `min_visible` keypoints show."""
     H, W = size
     rng = np.random.Generator(np.random.PCG64(seed))
     codes = stamp_codes()                                # (57,3,2,2)
@@ -131,15 +133,15 @@ def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: f
         while True:
             cam = random_camera(rng)
             q = cam.project_points(PITCH_ARRAY)
-            vis = (q[:, 2] != 0) & (q[:, 0] >= 0) & (q[:, 0] < W) & (q[:, 1] >= 0) & (q[:, 1] < H)
+            vis = (q[:, 2] != 0) & (q[:, 0] >= 0) & (q[:, 0] < 960) & (q[:, 1] >= 0) & (q[:, 1] < 540)
             if vis.sum() >= min_visible:
                 break
         owner_env = np.zeros((hc, wc), dtype=np.float32)
         cells = frames[b].reshape(3, hc, 2, wc, 2)       # view: [c, i, ky, j, kx]
         for k in np.nonzero(vis)[0]:
             p = q[k, :2] + rng.normal(0, jitter_px, 2)
-            cj = int(min(max(round(p[0] / 2.0), 0), wc - 1))
-            ci = int(min(max(round(p[1] / 2.0), 0), hc - 1))
+            cj = int(min(max(round(p[0] * wc / 960.0), 0), wc - 1))         # cell of the (hc, wc) stem / heatmap grid
+            ci = int(min(max(round(p[1] * hc / 540.0), 0), hc - 1))
             i0, i1, j0, j1 = max(ci - R, 0), min(ci + R, hc - 1), max(cj - R, 0), min(cj + R, wc - 1)
             env = env0[i0 - ci + R:i1 - ci + R + 1, j0 - cj + R:j1 - cj + R + 1]
             take = env > owner_env[i0:i1 + 1, j0:j1 + 1]                  # overlapping blobs: the stronger envelope owns the cell
@@ -147,5 +149,5 @@ def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: f
             stamp = 0.5 + 0.5 * env[None, :, None, :, None] * codes[k][:, None, :, None, :]     # (3,ni,2,nj,2)
             blk = cells[:, i0:i1 + 1, :, j0:j1 + 1, :]
             blk[...] = np.where(take[None, :, None, :, None], stamp, blk)
-            expect[b, k] = (2.0 * cj, 2.0 * ci, 1.0)
+            expect[b, k] = (cj * 960.0 / wc, ci * 540.0 / hc, 1.0)
     return frames, expect

@@ -143,3 +143,52 @@ def test_pipeline_overlapped_solve_matches_direct(sncal, cuda):
     oc = osolve.CameraCreatorOracle()
     o0 = oc(kps[0].cpu().numpy(), None)
     assert (o0 is None) == (cams[0] is None)
+
+
+def test_c4_at_size_w48_keypoint_and_w48_line_networks(sncal, cuda):
+    """C4 at its own size (export_line_result.py:85-131 -> prediction.py:105-124, 356-364): HRNet-W48 keypoint net and
+    HRNet-W48 line net on the same 960x540 frames, through CalibrationPipeline(line_net=...): two-peak decode, line
+    equations and the 30 intersection candidates stay on the device and feed the solve.
+      * line candidates: bit-identical to the oracle's join (oracle/lines.py) applied to the line net's OWN heatmaps;
+      * keypoints / cameras: the peaked workload (synth.py) drives the solve; records equal a direct solve call given the
+        same keypoints and line points; cameras are found for the stamped frames;
+      * the bf16 line net stays inside the bf16 drift bound of the fp32 engine on these frames."""
+    import bench
+    B = 4
+    sd_k = sncal.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1))
+    sd_l = bench.seeded_weights('line_hrnet_w48', seed=2)
+    frames, expect = sncal.synth.stamped_frames(B, seed=77)
+    x = torch.from_numpy(frames).to(cuda)
+    knet = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    knet.load_state_dict(sd_k)
+    lnet = sncal.HRNetHeatmap('line_hrnet_w48', dtype='bf16', device=cuda)
+    lnet.load_state_dict(sd_l)
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter',
+                             max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0,
+                             min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
+    pipe = sncal.CalibrationPipeline(knet, cc, line_net=lnet, line_sigma=3.0, line_scale=4, line_prob_thre=0.0)
+    kp, rec = pipe.submit(x)[:2]
+    pipe.join()
+    torch.cuda.synchronize()
+    # the line branch, step by step, on the line net's own heatmaps
+    heat_l = lnet(x)[-1]
+    assert heat_l.shape == (B, 23, 135, 240)
+    peaks = sncal.EHMPredictionTransform.mask_heat_points_gauss(heat_l, sigma=3.0)
+    ref_peaks = od.line_decode(heat_l.cpu().numpy(), 3.0, 1.0)
+    assert np.array_equal(peaks.cpu().numpy()[..., :2], ref_peaks[..., :2])
+    dev_pts = sncal.lines.lines_to_points_device(peaks, scale=4, prob_thre=0.0)
+    arr = ol.keypoints_array(peaks.cpu().numpy(), scale=4, prob_thre=0.0)
+    assert np.array_equal(dev_pts.cpu().numpy().view(np.uint32), arr.view(np.uint32))               # bit-identical candidates
+    # the pipeline's records == a direct solve on the same keypoints + line points
+    direct = cc.records(cc.solve_device(kp, dev_pts))
+    got = cc.records(rec)
+    for a, d in zip(got, direct):
+        assert a.status == d.status and a.rmse == d.rmse and list(a.rotation) == list(d.rotation)
+    vis = expect[..., 2] > 0
+    assert float((kp.cpu().numpy()[..., :2] == expect[..., :2]).all(-1)[vis].mean()) >= 0.99
+    assert sum(r.status != 0 for r in got) >= B - 1
+    # fp32 line engine on one frame: the bf16 line net stays close (softmax probabilities)
+    l32 = sncal.HRNetHeatmap('line_hrnet_w48', dtype='fp32', device=cuda)
+    l32.load_state_dict(sd_l)
+    h32 = l32(x[:1])[-1]
+    assert float((h32 - heat_l[:1]).abs().max()) <= 6e-2

@@ -1,0 +1,124 @@
+"""GPU: BASELINE config C5 -- HRNet-W48 with fp8 (OCP e4m3, CDNA4 block-scaled MFMA) arithmetic in the wide 3x3 stride-1
+convolutions, at 1920x1080, with the tolerance sweep north_star asks for: which layers run in fp8 vs how far the decoded
+keypoints and the solved cameras move from the exact-fp32 engine (the one pinned to the reference capture).
+
+The reference has no reduced-precision inference path (predict() is fp32, src/models/hrnet/metamodel.py:127-134), so there
+is no reference oracle for fp8 itself: the checks are (i) plumbing -- the fp8 kernel really runs, selection strings work,
+'none' reproduces the bf16 engine bit for bit; (ii) numerics -- the sweep table, with the bf16 engine as the zero line.
+Solve parity is against the build's own oracle only (OpenCV parity unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter', max_rmse=55.0, max_rmse_rel=5.0,
+          min_points=5, min_focal_length=10.0, min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
+SPECS = ['none', 'c384', 'stage4', 'stage3,stage4', 'c192,c384', 'all']
+
+
+def _weights(sncal, **kw):
+    import bench
+    return sncal.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), **kw)
+
+
+def test_fp8_plumbing_small(sncal, cuda):
+    """270x480 input (9x15 .. 68x120 maps): calibrate, select, run; 'none' == the bf16 engine bit for bit; 'all' runs the fp8
+    kernel for every wide conv and stays within a coarse distance of the bf16 engine; selection errors are refused."""
+    sd = _weights(sncal)
+    frames, _ = sncal.synth.stamped_frames(3, seed=5, size=(270, 480))
+    x = torch.from_numpy(frames).to(cuda)
+    nb = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    nb.load_state_dict(sd)
+    h16, k16 = nb.forward(x, want_heat=True, decode_size=(540, 960))
+    n8 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp8', device=cuda)
+    n8.load_state_dict(sd)
+    with pytest.raises(sncal._lib.SncalError):
+        n8.forward(x, want_heat=True)                              # no calibration yet
+    n8.calibrate_fp8(x)
+    n8.set_fp8_layers('none')
+    h0, k0 = n8.forward(x, want_heat=True, decode_size=(540, 960))
+    assert torch.equal(h0, h16) and torch.equal(k0, k16)
+    n8.set_fp8_layers('all')
+    n8.set_profiling(True)
+    h8, k8 = n8.forward(x, want_heat=True, decode_size=(540, 960))
+    prof = {p['kernel']: p for p in n8.get_profile()}
+    n8.set_profiling(False)
+    assert 'conv_tt<fp8,k3,s1,8x32x96>' in prof and 'conv_tt<bf16,k3,s1,8x32x96>' not in prof, sorted(prof)
+    assert torch.isfinite(h8).all()
+    d = (h8 - h16).abs()
+    assert float(d.mean()) < 0.5 and float(d.max()) < 8.0, (float(d.mean()), float(d.max()))
+    n8.set_fp8_layers('stage4,c384')
+    n8.set_profiling(True)
+    n8.forward(x, want_heat=True)
+    prof = {p['kernel']: p for p in n8.get_profile()}
+    assert 'conv_tt<fp8,k3,s1,8x32x96>' in prof and 'conv_tt<bf16,k3,s1,8x32x96>' in prof
+    with pytest.raises(sncal._lib.SncalError):
+        n8.set_fp8_layers('stage9')
+    with pytest.raises(sncal._lib.SncalError):
+        nb.set_fp8_layers('all')                                   # not an fp8 network
+
+
+def test_c5_w48_fp8_1080p_tolerance_sweep(sncal, cuda):
+    """C5 at its own size: W48, 1920x1080 (heatmaps 540x960, 1-px decode grid), peaked workload, B = 2.  For every layer
+    selection: keypoint-index agreement with the fp32 engine (over the keypoints the solver can use, and over all rows),
+    and the relative difference of the solved cameras' reprojection error.  The table goes to gpurun_out/ (committed under
+    profiles/); asserted: 'none' equals the bf16 engine, and the all-fp8 network still finds the stamped keypoints and
+    cameras with rmse within 5 % of the fp32 engine's (the measured numbers are far inside; see the table)."""
+    B = 2
+    sd = _weights(sncal)
+    frames, expect = sncal.synth.stamped_frames(B, seed=4242, size=(1080, 1920))
+    x = torch.from_numpy(frames).to(cuda)
+    vis = expect[..., 2] > 0
+    n32 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp32', device=cuda)
+    n32.load_state_dict(sd)
+    _, kp32 = n32.forward(x, want_heat=False, decode_size=(540, 960))
+    kp32 = kp32.cpu().numpy()
+    del n32
+    torch.cuda.empty_cache()
+    assert float((kp32[..., :2] == expect[..., :2]).all(-1)[vis].mean()) >= 0.99
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, **KW)
+    c32 = cc.solve_batch(kp32)
+    usable = kp32[..., 2] >= 0.2
+    nb = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    nb.load_state_dict(sd)
+    _, kpb = nb.forward(x, want_heat=False, decode_size=(540, 960))
+    del nb
+    n8 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp8', device=cuda)
+    n8.load_state_dict(sd)
+    n8.calibrate_fp8(x)
+    rows = []
+    for spec in SPECS:
+        n8.set_fp8_layers(spec)
+        n8.set_profiling(True)
+        _, kp = n8.forward(x, want_heat=False, decode_size=(540, 960))
+        prof = {p['kernel']: p for p in n8.get_profile()}
+        n8.set_profiling(False)
+        if spec == 'none':
+            assert torch.equal(kp, kpb)
+        kp = kp.cpu().numpy()
+        same = (kp[..., :2] == kp32[..., :2]).all(-1)
+        cams = cc.solve_batch(kp)
+        deltas = [abs(c.rmse - r.rmse) / r.rmse for c, r in zip(cams, c32) if c is not None and r is not None]
+        fp8_ms = prof.get('conv_tt<fp8,k3,s1,8x32x96>', {}).get('ms', 0.0)
+        bf_ms = prof.get('conv_tt<bf16,k3,s1,8x32x96>', {}).get('ms', 0.0)
+        rows.append({'fp8_layers': spec, 'index_agreement_usable': round(float(same[usable].mean()), 6),
+                     'index_agreement_all_rows': round(float(same.mean()), 6),
+                     'conf_delta_max_usable': round(float(np.abs(kp[..., 2] - kp32[..., 2])[usable].max()), 5),
+                     'cameras': sum(c is not None for c in cams), 'cameras_fp32': sum(c is not None for c in c32),
+                     'rmse_rel_delta_max': max(deltas) if deltas else None,
+                     'wide_conv_ms_fp8_kernel': round(fp8_ms, 3), 'wide_conv_ms_bf16_kernel': round(bf_ms, 3)})
+        print('FP8SWEEP', json.dumps(rows[-1]))
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open(os.path.join('gpurun_out', 'fp8_sweep_1080p.json'), 'w') as f:
+            json.dump({'workload': 'HRNet-W48 1920x1080, peaked heatmaps (synth.py), B=2, vs the exact-fp32 engine', 'rows': rows}, f, indent=1)
+    except OSError:
+        pass
+    full = rows[-1]
+    assert full['fp8_layers'] == 'all' and full['cameras'] == full['cameras_fp32'] == B
+    assert full['index_agreement_usable'] >= 0.95, full
+    assert full['rmse_rel_delta_max'] is not None and full['rmse_rel_delta_max'] <= 0.05, full

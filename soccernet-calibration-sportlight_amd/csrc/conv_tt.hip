@@ -282,8 +282,10 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     q = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), z));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs_out, voff[jr][e], soff[jr], 0);
-                if constexpr (FP8) {             // e4m3 twin for the next fp8 convolution: the ROUNDED bf16 value / scale, saturated
+                if constexpr (FP8) {             // e4m3 twin for the next fp8 convolution: the ROUNDED bf16 value / scale, saturated.
+                    // Packed BEFORE the bf16 store is issued: with the conversion after it, v_cvt_pk_fp8_f32 was allocated the
+                    // store's first data register and, under memory load, overwrote it before the store had read it -- isolated
+                    // wrong bf16 elements (first of an 8-channel group, magnitudes of fp8 codes), traced with per-launch checksums.
                     float w8[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) w8[k] = fminf(fmaxf((float)q[k] * M.out8_inv_scale, -448.f), 448.f);
@@ -293,7 +295,14 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], p1, true);
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const unsigned v8 = voff[jr][e] == 0x80000000u ? 0x80000000u : voff[jr][e] >> 1;
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)p0, (unsigned)p1}, rs_out8, v8, soff[jr] >> 1, 0);
+                    u32x4 qd = __builtin_bit_cast(u32x4, q);
+                    u32x2 pd = u32x2{(unsigned)p0, (unsigned)p1};
+                    asm volatile("" : "+v"(qd), "+v"(pd));      // both packs are complete, in registers of their own, before either store
+                    __builtin_amdgcn_raw_buffer_store_b128(qd, rs_out, voff[jr][e], soff[jr], 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(pd, rs_out8, v8, soff[jr] >> 1, 0);
+                    asm volatile("s_nop 1" ::: "memory");        // ... and two wait states before anything may reuse the data registers
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs_out, voff[jr][e], soff[jr], 0);
                 }
             }
         }
@@ -349,6 +358,14 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     for (int jr = 0; jr < NB; ++jr) asm volatile("" : "+v"(acc[mb][jr]) :: "memory");
                 if (t + 1 < NKS) __builtin_amdgcn_sched_barrier(0);
             }
+            // The token is handed on only when this wave's scaled MFMAs have COMPLETED (a dependent read of every accumulator).
+            // Measured on MI355X: when the partner wave of the SIMD starts its own v_mfma_scale_* while this wave's are still in
+            // the pipe, results are occasionally corrupt (isolated huge values, run-to-run differences: 3 of 9 runs; 0 of 12 with
+            // this wait; the plain bf16 MFMAs overlap between the two waves without harm).
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int jr = 0; jr < NB; ++jr) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[mb][jr][15]));
             near_end();
         } else {
             // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t

@@ -358,14 +358,6 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                     for (int jr = 0; jr < NB; ++jr) asm volatile("" : "+v"(acc[mb][jr]) :: "memory");
                 if (t + 1 < NKS) __builtin_amdgcn_sched_barrier(0);
             }
-            // The token is handed on only when this wave's scaled MFMAs have COMPLETED (a dependent read of every accumulator).
-            // Measured on MI355X: when the partner wave of the SIMD starts its own v_mfma_scale_* while this wave's are still in
-            // the pipe, results are occasionally corrupt (isolated huge values, run-to-run differences: 3 of 9 runs; 0 of 12 with
-            // this wait; the plain bf16 MFMAs overlap between the two waves without harm).
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int jr = 0; jr < NB; ++jr) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[mb][jr][15]));
             near_end();
         } else {
             // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t

@@ -1098,7 +1098,11 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         static const bool fp8_singles = getenv("SNCAL_FP8_SINGLES") != nullptr;          // debugging aid
         bool any_fp8 = false;
         for (int i = 0; i < n; ++i) any_fp8 = any_fp8 || net.layers[ops[i].conv].fp8_on;
-        if (any_fp8 && fp8_singles) return SNCAL_OK;          // *done stays false: the caller runs the members one by one (run_conv)
+        bool all_fp8 = true;
+        for (int i = 0; i < n; ++i) all_fp8 = all_fp8 && net.layers[ops[i].conv].fp8_on;
+        // a group that mixes fp8 and bf16 members (layer selection by width) cannot share one launch: *done stays false and the
+        // caller runs the members one by one (run_conv)
+        if (any_fp8 && (!all_fp8 || fp8_singles)) return SNCAL_OK;
         if (all_tt && couts <= TT_TABLE_MAX) {
             const int rc = run_conv_tt(net, ops, n, (int)(ops - net.ops.data()) * 4096 + sb, sb, ws, stream);
             *done = rc == SNCAL_OK;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the per-frame calibration hot path on MI355X (metric of BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c4] [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4] [--dtype bf16|fp32|fp8] [--size 540p|1080p]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of frames already resident in HBM (BASELINE config C3: HRNet-W48,
@@ -45,7 +45,8 @@ sys.path.insert(0, ROOT)
 # conv MACs of the reference's direct formulation x2
 FLOP_KEYPOINT_NET = 2 * 253910384640
 FLOP_LINE_NET = 2 * 185690000000
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+FLOP_KEYPOINT_NET_1080P = 2 * 1014180000000
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
 BATCH = 64
 SOLVER_KW = dict(conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter', lines_file=None,
                  max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0, min_points_per_plane=6,
@@ -78,7 +79,7 @@ def seeded_weights(cfg, seed):
 
 
 # ---- CPU baseline: the oracle on this host's cores, bounded sample --------------------------------
-def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0):
+def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0, nb=8):
     """torch-CPU fp32 forward at batch 8 on all physical cores (warm-up 2, median of up to 5 runs inside the budget),
     numpy decode, numpy camera solve single-process and on an all-cores process pool (the reference uses 16 workers,
     make_submit.py:25).  `frames` (>=8,3,540,960) CPU tensor, `kpts` decoded keypoints (n,57,3) to solve."""
@@ -92,7 +93,7 @@ def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0):
     cores = int(cores)
     cfg = hr.load_config(cfg_name)
     torch.set_num_threads(cores)
-    x = frames[:8].contiguous()
+    x = frames[:nb].contiguous()
     t_start = time.perf_counter()
     with torch.no_grad():
         for _ in range(2):                                           # warm-up (oneDNN primitive creation, thread pool)
@@ -136,7 +137,7 @@ def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0):
             pool_txt = f'pool unavailable ({type(e).__name__})'
     stages = {'forward': 1.0 / t_net, 'decode': 1.0 / t_dec, 'solve': fps_pool}
     return {'value': round(min(stages.values()), 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle (CPU restatement) on {cores} physical cores: HRNet-W48 960x540 fp32 torch-CPU forward, batch 8, '
+            'sample': f'oracle (CPU restatement) on {cores} physical cores: HRNet-W48 {frames.shape[3]}x{frames.shape[2]} fp32 torch-CPU forward, batch {x.shape[0]}, '
                       f'warm-up 2 + median of {len(runs)} runs = {t_net:.3f} s/frame ({1 / t_net:.2f} frames/s); numpy decode '
                       f'{t_dec * 1e3:.0f} ms/frame; numpy camera solve on the decoded keypoints {t_solve1 * 1e3:.0f} ms/frame single '
                       f'process, {pool_txt}; value = slowest stage of the pipelined three (BASELINE.md 4.5)',
@@ -183,7 +184,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+                    help="fp8: e4m3 arithmetic in the wide 3x3 convolutions (BASELINE config C5; calibrated on the first frames), the rest bf16")
+    ap.add_argument('--size', default='540p', choices=['540p', '1080p'], help='input frames 960x540 (the metric) or 1920x1080 (config C5)')
+    ap.add_argument('--fp8-layers', default='all', help="layer selection of --dtype fp8 (sncal_hrnet_set_fp8_layers)")
     ap.add_argument('--workload', default='c3', choices=['c3', 'c4'],
                     help='c3: HRNet-W48 keypoint net + decode + solve (the metric\'s configuration); c4: + the W48 line net, '
                          'its two-peak decode and the device line join in front of the solve')
@@ -230,9 +234,17 @@ def main():
             ln = sncal_amd.HRNetHeatmap('line_hrnet_w48', dtype=args.dtype, device=dev)
             ln.load_state_dict(sd_line)
             lnets.append(ln)
-    frames_cpu, expect = sncal_amd.synth.stamped_frames(B, seed=1000 + rank)     # synthetic frames, then resident in HBM
+    HW = (540, 960) if args.size == '540p' else (1080, 1920)
+    n_distinct = B if args.size == '540p' else min(B, 16)        # 1080p: 16 distinct frames, repeated (host memory / start-up time)
+    frames_cpu, expect = sncal_amd.synth.stamped_frames(n_distinct, seed=1000 + rank, size=HW)     # synthetic frames, then resident in HBM
     frames_cpu = torch.from_numpy(frames_cpu)
-    x = frames_cpu.to(dev)
+    reps = (B + n_distinct - 1) // n_distinct
+    x = frames_cpu.to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
+    expect = np.tile(expect, (reps, 1, 1))[:B]
+    if args.dtype == 'fp8':
+        for n in nets:
+            n.calibrate_fp8(x[:4])
+            n.set_fp8_layers(args.fp8_layers)
     cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **SOLVER_KW)
     pipes = [sncal_amd.CalibrationPipeline(nets[i], cc, decode_size=(540, 960), line_net=lnets[i] if c4 else None)
              for i in range(L)]
@@ -342,9 +354,10 @@ def main():
                 traffic = json.load(f).get(dom['kernel'])
         except OSError:
             pass
-        peak = PEAK_TFLOPS[args.dtype]
-        flop_frame = FLOP_KEYPOINT_NET + (FLOP_LINE_NET if c4 else 0)
-        wl = ('C4: HRNet-W48 keypoint net + HRNet-W48 line net, 960x540, batch 64 per GPU, decodes + device line join + batched camera solve (iterative_voter)'
+        peak = PEAK_TFLOPS['fp8' if 'fp8' in dom['kernel'] else 'bf16' if args.dtype == 'fp8' else args.dtype]
+        flop_frame = (FLOP_KEYPOINT_NET if args.size == '540p' else FLOP_KEYPOINT_NET_1080P) + (FLOP_LINE_NET if c4 else 0)
+        wl = (f'C5: HRNet-W48 1920x1080, batch {B} per GPU, {args.dtype} (fp8 layers: {args.fp8_layers}), heatmap 540x960 + decode + batched camera solve (iterative_voter)'
+              if args.size == '1080p' else 'C4: HRNet-W48 keypoint net + HRNet-W48 line net, 960x540, batch 64 per GPU, decodes + device line join + batched camera solve (iterative_voter)'
               if c4 else 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter) on the decoded keypoints')
         out = {
             'metric': 'frames/sec (HRNet-W48 960x540 + PnP)', 'value': round(world * B * args.steps / dt, 2),
@@ -368,9 +381,10 @@ def main():
         if world == 1 and not args.no_parity:
             for n in nets[1:] + lnets:
                 n._ws = None
-            out['parity'] = parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev)
+            npar = B if args.size == '540p' else min(B, 16)
+            out['parity'] = parity_leg(sncal_amd, cfg_name, sd, x[:npar], cc, kp_fast[:npar], rec_fast[:npar], dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf)
+            out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf, nb=8 if args.size == '540p' else 2)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -991,6 +991,8 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     TTParams tp;
     memset(&tp, 0, sizeof(tp));
     const bool fp8 = net.layers[ops[0].conv].fp8_on;
+    const sncal::LaunchEvents armed = sncal::launch_events();        // the profiling event pair belongs to the convolution launch,
+    sncal::launch_events() = sncal::LaunchEvents{};                  // not to the calibration / quantisation helpers in front of it
     for (int i = 0; i < n; ++i) {
         if (net.calibrating && net.tensors[ops[i].in].twin >= 0) {        // C5 calibration: max |x| of every candidate input tensor
             const Tensor& ti = net.tensors[ops[i].in];
@@ -1004,6 +1006,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         }
         tt_member(net, ops[i], sb, ws, tp.m[i]);
     }
+    sncal::launch_events() = armed;
     if (fp8) key += 1 << 30;                                               // fp8 plans have their own stage counts
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward

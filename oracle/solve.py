@@ -40,6 +40,23 @@ import numpy as np
 from . import camera_math as cm
 from .pitch import GOAL_LEFT, GOAL_RIGHT, GROUND, KEEP_POINTS, TOP_GATES, pitch_points
 
+# Stopping rules of the minimisers and the handling of a failed IAC factorisation.  Default: run to convergence / drop the
+# homography camera (the build's specification, shared with csrc/solve.hip).  tools/solve_schedule_sweep.py switches them to
+# bound the UNPINNED gap to OpenCV: `opencv_stops()` = calibrateCamera's default criteria of 30 joint iterations and
+# solvePnPRefineLM's criteria (20000, 1e-5) on step and residual (SURVEY 8c notes; the damping schedule stays the build's
+# own); `iac_failure='reference'` = go on with K = I as prediction.py:514 does.
+STOP = dict(joint_iters=60, pose_iters=100, pose_eps=1e-10, pose_res_eps=0.0, iac_failure='drop')
+COUNTERS = dict(iac_failures=0)
+
+
+def opencv_stops():
+    STOP.update(joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5)
+
+
+def converged_stops():
+    STOP.update(joint_iters=60, pose_iters=100, pose_eps=1e-10, pose_res_eps=0.0)
+
+
 P64 = pitch_points()
 P32 = P64.astype(np.float32).astype(np.float64)     # what cv2 sees: np.array(..., dtype=np.float32)
 PLANES = (('groundplane', GROUND, False), ('goal_left', GOAL_LEFT, True), ('goal_right', GOAL_RIGHT, True))
@@ -274,6 +291,8 @@ def refine_pose_lm(R, t, K4, X, uv, max_iters: int = 100, eps: float = 1e-10):
             J[row::2, 2] = d[:, 1] * Xc[:, 0] - d[:, 0] * Xc[:, 1]
             J[row::2, 3:6] = d
         A, g = J.T @ J, J.T @ r
+        if STOP['pose_res_eps'] > 0 and np.abs(r).max() < STOP['pose_res_eps']:
+            break
         improved = False
         for _try in range(12):
             step = chol_solve(A + np.diag(np.diag(A)) * lam, -g)
@@ -427,7 +446,7 @@ def calibrate_planes(views, weights, img_wh):
         return c
     lam = 1e-3
     c0 = total_cost(f, poses)
-    for _ in range(60):
+    for _ in range(STOP['joint_iters']):
         blocks = []
         aff, gf = 0.0, 0.0
         for (Xp, uv), wgt, (R_, t_) in zip(views, weights, poses):
@@ -517,7 +536,8 @@ class Cam:
         self.rotation, self.position = R, -R.T @ t
 
     def refine_camera(self, ids, uv):
-        R, t = refine_pose_lm(self.rotation, -self.rotation @ self.position, self.K4, P64[ids], uv)
+        R, t = refine_pose_lm(self.rotation, -self.rotation @ self.position, self.K4, P64[ids], uv,
+                              max_iters=STOP['pose_iters'], eps=STOP['pose_eps'])
         self.rotation, self.position = R, -R.T @ t
 
     def projection_rmse(self, ids, uv):
@@ -569,7 +589,15 @@ def camera_from_homography(ids, uv, img_wh=(960, 540)):
     cam = Cam(*img_wh)
     ok, fx, fy = cm.k_from_plane_homography(H, (img_wh[0] / 2, img_wh[1] / 2))
     if not ok:
-        return None      # build deviation: the reference ignores the failure flag (:514, quirk Q5) and goes on with K = I
+        COUNTERS['iac_failures'] += 1
+        if STOP['iac_failure'] != 'reference':
+            return None      # build deviation: the reference ignores the failure flag (:514, quirk Q5) and goes on with K = I
+        # the reference's path: Camera() keeps calibration = eye(3), focal lengths 1, principal point (w/2, h/2) for project_point
+        cam.calibration = np.eye(3)
+        cam.xfocal_length = cam.yfocal_length = 1.0
+        cam.solve_pnp(ids, uv)
+        cam.refine_camera(ids, uv)
+        return cam, cam.projection_rmse(ids, uv)
     cam.xfocal_length, cam.yfocal_length = fx, fy
     cam.calibration = np.array([[fx, 0, img_wh[0] / 2], [0, fy, img_wh[1] / 2], [0, 0, 1.0]])
     cam.solve_pnp(ids, uv)

@@ -10,7 +10,7 @@ from .metamodel import HRNetMetaModel, EHMMetaModel, load_model  # noqa: F401
 from .camera import Camera  # noqa: F401
 from .prediction import CameraCreator  # noqa: F401
 from .pitch import PITCH_POINTS, INTERSECTON_TO_PITCH_POINTS  # noqa: F401
-from . import lines, pitch, prediction, camera, synth, dist, pipeline, interop, evaluate, jpeg, submit, loss  # noqa: F401
+from . import lines, pitch, prediction, camera, synth, dist, pipeline, interop, evaluate, jpeg, submit, loss, annotations  # noqa: F401
 from .evaluate import CameraEvaluator  # noqa: F401
 from .jpeg import JpegDecoder  # noqa: F401
 from .pipeline import CalibrationPipeline  # noqa: F401

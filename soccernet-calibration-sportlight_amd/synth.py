@@ -151,3 +151,45 @@ def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: f
             blk[...] = np.where(take[None, :, None, :, None], stamp, blk)
             expect[b, k] = (cj * 960.0 / wc, ci * 540.0 / hc, 1.0)
     return frames, expect
+
+
+# ---- synthetic annotations (N4 geometry tests): the pitch's lines and circles as a SoccerNet annotator would click them ----
+def synthetic_annotation(seed: int = 0, pts_per_line: int = 6, noise_px: float = 0.3):
+    """{annotation class: [(x, y) normalised to the 960x540 image]} for one sampled camera: every pitch line that runs through
+    at least two template intersections (sampled between its extreme intersection points) and the three circles, projected,
+    clipped to the image, with click noise.  Also returns the camera."""
+    from .lines import LINE_INTERSECTIONS
+    from .pitch import INTERSECTON_TO_PITCH_POINTS, PITCH_POINTS
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = random_camera(rng)
+    by_line = {}
+    for idx, pair in LINE_INTERSECTIONS.items():
+        for name in pair:
+            by_line.setdefault(name, []).append(np.asarray(PITCH_POINTS[INTERSECTON_TO_PITCH_POINTS[idx]], dtype=np.float64))
+    world = {}
+    for name, pts in by_line.items():
+        pts = np.array(pts)
+        if len(pts) < 2:
+            continue
+        span = pts.max(axis=0) - pts.min(axis=0)
+        ax = int(np.argmax(span))
+        a, b = pts[np.argmin(pts[:, ax])], pts[np.argmax(pts[:, ax])]
+        world[name] = a[None] + np.linspace(0.0, 1.0, 4 * pts_per_line)[:, None] * (b - a)[None]
+    R = 9.15
+    ang = np.linspace(0, 2 * np.pi, 48, endpoint=False)
+    world['Circle central'] = np.c_[R * np.cos(ang), R * np.sin(ang), np.zeros_like(ang)]
+    for name, cx, sgn in (('Circle left', -41.5, 1.0), ('Circle right', 41.5, -1.0)):
+        arc = np.c_[cx + R * np.cos(ang), R * np.sin(ang), np.zeros_like(ang)]
+        world[name] = arc[sgn * (arc[:, 0] - sgn * -36.0) > 0] if sgn > 0 else arc[arc[:, 0] < 36.0]
+    out = {}
+    for name, w in world.items():
+        q = cam.project_points(w)
+        ok = (q[:, 2] != 0) & (q[:, 0] >= 0) & (q[:, 0] <= 960) & (q[:, 1] >= 0) & (q[:, 1] <= 540)
+        p = q[ok, :2]
+        if len(p) < 2:
+            continue
+        if len(p) > pts_per_line and not name.startswith('Circle'):
+            p = p[np.linspace(0, len(p) - 1, pts_per_line).round().astype(int)]
+        p = p + rng.normal(0, noise_px, p.shape)
+        out[name] = [(float(x) / 960.0, float(y) / 540.0) for x, y in p]
+    return out, cam

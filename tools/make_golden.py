@@ -475,6 +475,53 @@ def gen_target():
     np.savez_compressed(os.path.join(GOLD, 'target.npz'), **out)
 
 
+def gen_annotations():
+    """N4 geometry: the reference's get_intersections (src/datatools/intersections.py:99-124 -> ellipse.py:326-400) on synthetic
+    annotations.  Its two third-party calls are replaced by the build's own routines -- `ellipse.LsqEllipse().fit(X).coefficients`
+    by annotations.fit_ellipse, `cv2.findHomography(src, dst, RANSAC, thr)` by annotations.homography_ransac -- so the capture
+    pins everything the reference computes in numpy: line fits and the recursive intersection, tangent points, circle x line
+    with the local refinement, the Top / Bottom choice, the image-bounds filter and the control flow around them."""
+    import sncal_amd
+    from sncal_amd import annotations as an
+
+    class Fit:
+        def fit(self, X):
+            q = an.fit_ellipse(np.asarray(X, dtype=np.float64))
+            self.coefficients = list(q) if q is not None else []
+            return self
+    sys.modules['ellipse'].LsqEllipse = Fit
+    sys.modules['cv2'].findHomography = lambda src, dst, method, thr: (an.homography_ransac(src, dst, thr), None)
+    import src.datatools.ellipse as rel
+    rel.LsqEllipse = Fit
+    from src.datatools.intersections import get_intersections
+    cases = []
+    for seed in range(24):
+        pts, _ = sncal_amd.synth.synthetic_annotation(seed)
+        if seed % 5 == 4:                                   # drop a few classes: exercises the homography fill / the mask
+            for k in list(pts)[::3]:
+                pts.pop(k)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref, mask = get_intersections({k: list(v) for k, v in pts.items()})
+        mine, mmask = an.get_intersections(pts)
+        worst = 0.0
+        for i in range(57):
+            r, m = ref.get(i), mine.get(i)
+            assert (r is None) == (m is None), (seed, i, r, m)
+            if r is not None:
+                worst = max(worst, abs(r[0] - m[0]), abs(r[1] - m[1]))
+        assert sorted(mask) == sorted(mmask), (seed, mask, mmask)
+        assert worst < 1e-6, (seed, worst)
+        arr = np.full((57, 2), np.nan)
+        for i in range(57):
+            if ref.get(i) is not None:
+                arr[i] = ref[i]
+        cases.append({'points': {k: [list(map(float, p)) for p in v] for k, v in pts.items()}, 'labels': arr.tolist(), 'mask': sorted(map(int, mask))})
+    with open(os.path.join(GOLD, 'annotations.json'), 'w') as f:
+        json.dump(cases, f)
+    n = sum(int(np.isfinite(np.array(c['labels'])[:, 0]).sum()) for c in cases)
+    print('annotations ok:', len(cases), 'frames,', n, 'labels')
+
+
 def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, batch=1):
     from oracle import hrnet_ref as hr, decode as od
     cfg = hr.load_config(cfg_name)
@@ -533,13 +580,15 @@ def gen_hrnet(name, cfg_name, hw, seed, head_gain, line=False, store_full=True, 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'lines', 'evaluator', 'evaluator_batch', 'jpeg', 'target', 'hrnet']
+    which = sys.argv[1:] or ['pitch', 'decode', 'camera', 'annotations', 'lines', 'evaluator', 'evaluator_batch', 'jpeg', 'target', 'hrnet']
     if 'pitch' in which:
         gen_pitch()
     if 'decode' in which:
         gen_decode()
     if 'camera' in which:
         gen_camera()
+    if 'annotations' in which:
+        gen_annotations()
     if 'lines' in which:
         gen_lines()
     if 'evaluator_batch' in which:

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""How much of the camera solve depends on the parts that cannot be pinned to OpenCV offline?  (VERDICT r1 task 7)
+
+The solve's arithmetic lives in opencv-python 4.7.0.72 (not installable here): the oracle (and the HIP kernel, which follows the
+same specification) runs every minimiser to convergence, OpenCV stops calibrateCamera after <= 30 joint iterations and
+solvePnPRefineLM on criteria (20000, 1e-5), and the reference ignores a failed IAC factorisation (prediction.py:514) where the
+build drops the homography camera.  This script runs the ORACLE (CPU, numpy) on N synthetic frames (SURVEY 8d recipe: sampled
+broadcast cameras, sigma-px noise, 3 % outliers) under
+    A  the build's specification (convergence, drop on IAC failure)
+    B  OpenCV-like stopping rules
+    C  A + the reference's continue-with-K=I on IAC failure
+and reports how many frames change None-ness or move their reprojection error by more than 1e-4 relative.  It BOUNDS the
+unpinned gap under the stated assumptions; it is not OpenCV parity.   python tools/solve_schedule_sweep.py [N] [procs]
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(seed):
+    from oracle import solve, synth
+    sigma = (0.5, 1.0, 2.0)[seed % 3]
+    kp, _ = synth.synth_keypoints(seed, sigma_px=sigma)
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for mode in 'ABC':
+            solve.converged_stops()
+            solve.STOP['iac_failure'] = 'drop'
+            if mode == 'B':
+                solve.opencv_stops()
+            if mode == 'C':
+                solve.STOP['iac_failure'] = 'reference'
+            solve.COUNTERS['iac_failures'] = 0
+            if mode == 'C' and out['A'][2] == 0:
+                out['C'] = out['A']                       # no IAC failure on this frame: C == A by construction
+                continue
+            cam = solve.CameraCreatorOracle()(kp, None)
+            out[mode] = (None if cam is None else float(cam.rmse), None if cam is None else cam.tag, solve.COUNTERS['iac_failures'])
+    return seed, sigma, out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, (os.cpu_count() or 2) - 1)
+    t0 = time.time()
+    with Pool(procs) as pool:
+        res = pool.map(run, range(n), chunksize=8)
+    summ = {'frames': n, 'seconds': round(time.time() - t0, 1), 'procs': procs,
+            'note': 'oracle-vs-oracle; bounds the unpinned OpenCV gap under SURVEY 8c stopping-rule notes, not OpenCV parity'}
+    for mode, name in (('B', 'opencv_like_stops_vs_convergence'), ('C', 'reference_iac_continue_vs_drop')):
+        noneness, moved, rel = 0, 0, []
+        tags = 0
+        for _, _, o in res:
+            a, b = o['A'], o[mode]
+            if (a[0] is None) != (b[0] is None):
+                noneness += 1
+            elif a[0] is not None:
+                r = abs(a[0] - b[0]) / a[0]
+                rel.append(r)
+                moved += r > 1e-4
+                tags += a[1] != b[1]
+        summ[name] = {'none_ness_changed': noneness, 'rmse_moved_more_than_1e-4_rel': int(moved), 'chosen_camera_tag_changed': tags,
+                      'rel_rmse_diff_max': float(max(rel)) if rel else None,
+                      'rel_rmse_diff_p99': float(np.percentile(rel, 99)) if rel else None,
+                      'cameras_in_both': len(rel)}
+    summ['frames_with_an_iac_failure'] = sum(1 for _, _, o in res if o['A'][2] > 0)
+    summ['cameras_found_spec'] = sum(1 for _, _, o in res if o['A'][0] is not None)
+    print(json.dumps(summ, indent=1))
+    out = os.path.join(ROOT, 'profiles', f'r02_solve_schedule_sweep_{n}.json')
+    with open(out, 'w') as f:
+        json.dump(summ, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -7,7 +7,8 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         m = re.search(r'conv_(?:group_)?kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
-        if m: k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
+        if 'conv_tt_kernel' in k: k = 'conv_tt<%s,k3,s1,8x32x96>' % ('fp8' if ('ILb1' in k or '<true>' in k) else 'bf16')
+        elif m: k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
         else:
             m2 = re.search(r'conv_(?:group_)?kernel<.*?(\d), (\d), (\d), (\d)>', k)
             k = 'conv<NI%s,MI%s,G%s>' % m2.groups()[:3] if m2 else ('head_fused' if 'head_fused' in k else k[:48])

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (on the GPU box): tools/round_profile.sh TAG -- the bench lines, the rocprofv3 kernel stats of the same command and
+# the two PMC passes a round's profiles/ entries are made from.  Outputs under gpurun_out/TAG/.
+tag=${1:-rXX}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --dtype fp8 --no-cpu-baseline > $O/bench_c3_fp8.json 2> $O/bench_c3_fp8.err
+python bench.py --dtype fp8 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5_fp8.err
+python bench.py --dtype bf16 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
+find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find $O/prof -name "*.csv" -size +2M -delete
+cd $R
+PMC_B=64 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" > $O/pmc.log 2>&1
+head -c 1500 $O/bench_c3.json; echo; head -c 600 $O/bench_c4.json; echo; head -c 600 $O/bench_c3_fp8.json; echo; head -c 600 $O/bench_c5_fp8.json; echo; head -c 600 $O/bench_c5_bf16.json; echo
+head -8 $O/kernel_stats.csv; tail -30 $O/pmc.log

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libsncal.so')
+LIB_PATH = os.environ.get('SNCAL_LIB_PATH') or os.path.join(_PKG, 'libsncal.so')     # override: A/B runs of two builds
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -4,21 +4,24 @@
 // as two convolutions it moves x (read) + mid (write) + mid (read) + x (residual read) + out (write) = 5 tensor
 // passes; fused it reads x once (with a 2-pixel halo that the caches absorb) and writes out once.
 //
-// Workgroup = 4 waves, output tile 12 rows x 14 columns:
-//   x halo   16 x 18 pixels x 48 ch  -> LDS once (LDS-DMA, zero fill outside the image), also serves as the residual
-//   conv1    mid = 14 x 16 pixels (the output tile + 1 pixel ring) in 14 row-fragments of 16 pixels; positions
-//            outside the image are written as zeros (conv2's zero padding), ReLU'd, bf16 -> LDS
-//   conv2    12 row-fragments (lanes 14/15 of a fragment recompute column 13 and are not stored)
-// Weights come in four 21 KB chunks (conv1 / conv2 x two 24-channel K-chunks), in the SAME fragment-ordered packing
-// the generic conv kernel uses for (MI = 3, G = 3), so the layers' packed weights and folded-BN shifts are shared and
-// the results are bit-identical to the two-kernel path (same MFMA order, same bf16 rounding of mid).
-// Only the first staging round is exposed: LDS regions are time-shared so that every later chunk is in flight under
-// MFMAs --   W: W1c0 -> W2c0        M: W1c1 -> mid        X: x halo -> W2c1 (after the residual moved to registers)
-// LDS 77.5 KB -> two workgroups per CU.
+// Workgroup = 4 waves (one per SIMD), PERSISTENT, one per CU; output tile 16 rows x 14 columns:
+//   weights  conv1 + conv2, four 21 KB chunks (conv x 24-channel K-chunk), RESIDENT in LDS for the life of the workgroup, in the
+//            SAME fragment-ordered packing the generic conv kernel uses for (MI = 3, G = 3): the layers' packed weights and
+//            folded-BN shifts are shared and the results are bit-identical to the two-kernel path (same MFMA order, same bf16
+//            rounding of mid)
+//   x halo   20 x 18 pixels x 48 ch  -> LDS (LDS-DMA, zero fill outside the image); the next tile's halo is requested as soon as
+//            conv1 and the residual read are done with this one and lands under conv2
+//   conv1    mid = 18 x 16 pixels (the output tile + 1 pixel ring) in 18 row-fragments of 16 pixels; positions outside the
+//            image are written as zeros (conv2's zero padding), ReLU'd, bf16 -> LDS
+//   conv2    16 row-fragments (lanes 14/15 of a fragment recompute column 13 and are not stored)
+//   stores   packed in registers and issued after the NEXT tile's opening barrier, so that the wait for the halo DMA (vmcnt
+//            counts loads and stores together) never waits for a store
+// LDS 84 + 40 + 31.5 = 155.5 KB -> one workgroup per CU; two barriers per tile.
 #include "bblock.hpp"
 #include "common.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace sncal {
@@ -28,66 +31,89 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int BB_TH = 12, BB_TW = 14;            // output tile
+constexpr int BB_TH = 16, BB_TW = 14;            // output tile
 constexpr int BB_MH = BB_TH + 2, BB_MW = 16;     // mid tile (rows, fragment width)
 constexpr int BB_XH = BB_TH + 4, BB_XW = 18;     // x halo tile
 constexpr int BB_PS = 112;                       // LDS bytes per pixel: 6 k-groups + 1 padding slot (bank spread)
 constexpr int BB_NKS = 7, BB_MI = 3;             // k-steps per 24-channel chunk (27 k-groups -> 28), 48 output channels
-constexpr int BB_WBYTES = BB_NKS * BB_MI * 1024;
+constexpr int BB_WBYTES = BB_NKS * BB_MI * 1024; // one (conv, K-chunk) of packed weights: 21 KB
 constexpr int BB_XROW = 2048;                    // LDS bytes per halo row: two 1 KB DMA pieces (126 of 128 slots used)
 constexpr int BB_XBYTES = BB_XH * BB_XROW;
 constexpr int BB_MIDBYTES = BB_MH * BB_MW * BB_PS;
-constexpr int BB_LDS = BB_XBYTES + BB_MIDBYTES + BB_WBYTES;
+constexpr int BB_LDS = 4 * BB_WBYTES + BB_XBYTES + BB_MIDBYTES;
+constexpr int BB_PF = 1;                         // operand prefetch distance in k-steps
+constexpr int BB_NW = 8;                         // waves per workgroup: two per SIMD
+constexpr int BB_J1 = (BB_MH + BB_NW - 1) / BB_NW, BB_J2 = BB_TH / BB_NW;      // pixel fragments (tile rows) per wave: conv1 (at most), conv2
+static_assert(BB_TH % BB_NW == 0 && BB_J1 == BB_J2 + 1 && BB_LDS <= 160 * 1024, "tile rows split evenly over the waves; one workgroup per CU");
 
-__global__ __launch_bounds__(256, 2) void bblock48_kernel(const BBlockParams p) {
+// PERSISTENT (round 2): one workgroup of four waves per CU walks a contiguous range of tiles with the block's whole weight set
+// (conv1 + conv2, 4 x 21 KB) RESIDENT in LDS.  The round-1 kernel launched one workgroup per tile and staged those 84 KB for
+// every 12 x 14 output pixels (13,824 workgroups, 1.16 GB of weight traffic per launch, four staging rounds with their barriers
+// per tile): a workgroup spent 80 % of its life outside its MFMA phases.  Now a tile costs its x halo (one DMA round that lands
+// under the previous tile's conv2), two barriers and its MFMAs.  Same packed weights, same K order, same bf16 rounding of
+// mid as the two-kernel path -> bit-identical results (tested).
+// One LDS-DMA piece (64 lanes x 16 bytes -> 1 KB at LDS byte address `lds_addr`) as inline assembly.  The builtin form makes hipcc's
+// wait-count pass treat every later ds_read as a possible reader of the DMA's destination: it put `s_waitcnt vmcnt(0)` in front of
+// conv2's first fragment reads -- i.e. waited for the NEXT tile's halo to land before multiplying -- and, because the loop-top wait
+// is inline assembly it cannot see, `vmcnt(2..0)` into conv1's first k-step, which waited for the previous tile's STORES.  Together
+// ~3k of 13k clk per tile.  Ordering is explicit here (vmcnt(0) + barrier at the top of every tile).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_piece(i32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4_t raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return i32x4_t{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+
+__global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const s_x = smem;
-    char* const s_mid = smem + BB_XBYTES;
-    char* const s_w = smem + BB_XBYTES + BB_MIDBYTES;
+    char* const s_w = smem;                                       // W1c0, W1c1, W2c0, W2c1
+    char* const s_x = smem + 4 * BB_WBYTES;
+    char* const s_mid = s_x + BB_XBYTES;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, ln = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
-    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y;
-    const int n = tile / p.tiles_y;
-    const int oy0 = ty * BB_TH, ox0 = tx * BB_TW;
 
-    unsigned long long* const trc = p.trace ? p.trace + (size_t)blockIdx.x * 16 : nullptr;
-    auto stamp = [&](int slot) { if (trc && tid == 0) trc[slot] = __builtin_amdgcn_s_memtime(); };
-    if (trc && tid == 0) trc[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    stamp(1);
+    // tiles of this workgroup: the launch's tiles are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8);
+    // the workgroups of an XCD take consecutive tiles of its range, so neighbouring halos meet in one L2
+    const int per_xcd = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, wx = (int)blockIdx.x >> 3;
+    const int n_tiles = p.N * p.tiles_y * p.tiles_x;
+    const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
+    int t = t_lo + wx;
+
     const size_t img_bytes = (size_t)p.H * p.W * 48 * 2;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.x)) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, 2 * BB_WBYTES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, 2 * BB_WBYTES, 0x00020000);
-    auto issue_w = [&](const __amdgpu_buffer_rsrc_t rs, char* dst, int chunk) {
-        for (int i = wave; i < BB_NKS * BB_MI; i += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + i * 1024), 16, (unsigned)(lane * 16),
-                                                     (unsigned)(chunk * BB_WBYTES + i * 1024), 0, 0);
-    };
-    issue_w(rs_w1, s_w, 0);
-    // x halo, row-aligned: a halo row (18 pixels x 7 slots = 126 slots) is two 64-slot DMA pieces, so a lane's part of
-    // the address (pixel-in-row, k-group, left/right bounds) is the same for every row and the row rides in the scalar
+    for (int i = wave; i < 2 * BB_NKS * BB_MI; i += BB_NW) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_void*)(s_w + i * 1024), 16, (unsigned)(lane * 16), (unsigned)(i * 1024), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_void*)(s_w + 2 * BB_WBYTES + i * 1024), 16, (unsigned)(lane * 16), (unsigned)(i * 1024), 0, 0);
+    }
+    // x halo of tile `tile`, row-aligned: a halo row (18 pixels x 7 slots = 126 slots) is two 64-slot DMA pieces, so a lane's
+    // part of the address (pixel-in-row, k-group, left/right bounds) is the same for every row and the row rides in the scalar
     // offset -- no per-piece VALU work.  Slot 6, slots 126/127 and outside-image pixels read out of range -> zeros.
-    unsigned xv[2];
+    const unsigned x_lds = (unsigned)(__UINTPTR_TYPE__)(lds_void*)s_x;      // LDS byte address of the halo region
+    auto issue_x = [&](int n, int oy0, int ox0) {
+        const i32x4_t rs_x = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_bytes, (unsigned)img_bytes);
+        unsigned xv[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const unsigned slot = (unsigned)(k * 64 + lane);
-        const unsigned px = slot / 7u, cg = slot - px * 7u;
-        const int ix = ox0 - 2 + (int)px;
-        const bool ok = (cg < 6u) & (px < (unsigned)BB_XW) & ((unsigned)ix < (unsigned)p.W);
-        xv[k] = ok ? (unsigned)(ix * 96 + (int)cg * 16) : 0x80000000u;
-    }
-    for (int j = wave; j < 2 * BB_XH; j += 4) {
-        const int hy = j >> 1, iy = oy0 - 2 + hy;
-        const bool rowok = (unsigned)iy < (unsigned)p.H;
-        const unsigned voff = rowok ? ((j & 1) ? xv[1] : xv[0]) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(s_x + j * 1024), 16, voff, rowok ? (unsigned)(iy * p.W * 96) : 0u, 0, 0);
-    }
-    // conv1's second chunk goes LAST, into the (still unused) mid region: the first MFMA phase only waits for what was
-    // issued before it (loads complete in order; wave 0 owns 6 of the 21 pieces, the others 5) and W1c1 lands under it
-    issue_w(rs_w1, s_mid, 1);
+        for (int k = 0; k < 2; ++k) {
+            const unsigned slot = (unsigned)(k * 64 + lane);
+            const unsigned px = slot / 7u, cg = slot - px * 7u;
+            const int ix = ox0 - 2 + (int)px;
+            const bool ok = (cg < 6u) & (px < (unsigned)BB_XW) & ((unsigned)ix < (unsigned)p.W);
+            xv[k] = ok ? (unsigned)(ix * 96 + (int)cg * 16) : 0x80000000u;
+        }
+        for (int j = wave; j < 2 * BB_XH; j += BB_NW) {
+            const int hy = j >> 1, iy = oy0 - 2 + hy;
+            const bool rowok = (unsigned)iy < (unsigned)p.H;
+            const unsigned voff = rowok ? ((j & 1) ? xv[1] : xv[0]) : 0x80000000u;
+            dma_piece(rs_x, x_lds + (unsigned)j * 1024u, voff, rowok ? (unsigned)(iy * p.W * 96) : 0u);
+        }
+    };
+    // tile coordinates: decoded once (scalar divisions), then advanced by the stride of the walk
+    int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tn = t / (p.tiles_x * p.tiles_y);
+    const int step_x = per_xcd % p.tiles_x, step_y = per_xcd / p.tiles_x;      // per_xcd tiles further = step_y rows and step_x columns
+    if (t < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);
 
     // fragment offsets of k-step s within a 24-channel chunk: k-group kg = 4s + g -> (tap, cg); same order as pack_layer
     auto frag_off = [&](int s, int row_pitch, int chunk) -> int {
@@ -97,144 +123,188 @@ __global__ __launch_bounds__(256, 2) void bblock48_kernel(const BBlockParams p) 
         const int dy = tap / 3, dx = tap - dy * 3;
         return dy * row_pitch + dx * BB_PS + (chunk * 3 + cg) * 16;
     };
-    f32x4 acc[BB_MI][4];
-    auto init_acc = [&](const float* bias) {
+    f32x4 acc[BB_MI][BB_J1];
+    // folded-BN shifts of the lane's four channels per 16-channel block, loaded ONCE (a global load per tile sat in front of each
+    // conv's first MFMA: ~1k clk of exposed L2 latency twice per tile)
+    float4 bias1[BB_MI], bias2[BB_MI];
 #pragma unroll
-        for (int mi = 0; mi < BB_MI; ++mi) {
-            const float4 bs = *reinterpret_cast<const float4*>(bias + mi * 16 + g * 4);
+    for (int mi = 0; mi < BB_MI; ++mi) {
+        bias1[mi] = *reinterpret_cast<const float4*>(p.b1 + mi * 16 + g * 4);
+        bias2[mi] = *reinterpret_cast<const float4*>(p.b2 + mi * 16 + g * 4);
+    }
+    auto init_acc = [&](const float4 (&bias)[BB_MI]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mi][j] = f32x4{bs.x, bs.y, bs.z, bs.w};
-        }
+        for (int mi = 0; mi < BB_MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < BB_J1; ++j) acc[mi][j] = f32x4{bias[mi].x, bias[mi].y, bias[mi].z, bias[mi].w};
     };
     // one K-chunk of one conv: NJ pixel fragments per wave from the LDS image `src`
-    auto mma_chunk = [&](const char* wbuf, const char* src, const int (&boff)[4], int row_pitch, int chunk, int nj) {
-        bf16x8 a[2][BB_MI], b[2][4];
-        {
-            const int off = frag_off(0, row_pitch, chunk);
+    auto mma_chunk = [&](const char* wbuf, const char* src, const int (&boff)[BB_J1], int row_pitch, int chunk, auto nj_c) {
+        constexpr int nj = decltype(nj_c)::value;
+        // Operand fragments are read one k-step ahead of their MFMAs, and the reads are INTERLEAVED with the MFMAs (one ds_read
+        // behind each of the first MFMAs, sched_group_barrier): this wave is alone on its SIMD, so while it issues a block of seven
+        // or eight reads (plus their address adds) the matrix pipe drains -- with "all reads, then all MFMAs" a k-step took ~330 clk
+        // whether it held 15 MFMAs or 12.  Read order = order of first use (A0, the B fragments, A1, A2).
+        bf16x8 a[2][BB_MI], b[2][nj];
+        auto load = [&](int s, int buf) {
+            const int off = frag_off(s, row_pitch, chunk);
+            a[buf][0] = *reinterpret_cast<const bf16x8*>(wbuf + ((s * BB_MI + 0) * 64 + lane) * 16);
 #pragma unroll
-            for (int mi = 0; mi < BB_MI; ++mi) a[0][mi] = *reinterpret_cast<const bf16x8*>(wbuf + (mi * 64 + lane) * 16);
+            for (int j = 0; j < nj; ++j) b[buf][j] = *reinterpret_cast<const bf16x8*>(src + boff[j] + off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < nj) b[0][j] = *reinterpret_cast<const bf16x8*>(src + boff[j] + off);
-        }
+            for (int mi = 1; mi < BB_MI; ++mi) a[buf][mi] = *reinterpret_cast<const bf16x8*>(wbuf + ((s * BB_MI + mi) * 64 + lane) * 16);
+        };
+        load(0, 0);
 #pragma unroll
         for (int s = 0; s < BB_NKS; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < BB_NKS) {
-                const int off = frag_off(s + 1, row_pitch, chunk);
-#pragma unroll
-                for (int mi = 0; mi < BB_MI; ++mi)
-                    a[nxt][mi] = *reinterpret_cast<const bf16x8*>(wbuf + (((s + 1) * BB_MI + mi) * 64 + lane) * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < nj) b[nxt][j] = *reinterpret_cast<const bf16x8*>(src + boff[j] + off);
-            }
+            const int cur = s & 1;
+            if (s + 1 < BB_NKS) load(s + 1, cur ^ 1);
 #pragma unroll
             for (int mi = 0; mi < BB_MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nj) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mi], b[cur][j], acc[mi][j], 0, 0, 0);
-            if (s + 1 < BB_NKS) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < nj; ++j)
+                    acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mi], b[cur][j], acc[mi][j], 0, 0, 0);
+            if (s + 1 < BB_NKS) {
+#pragma unroll
+                for (int i = 0; i < BB_MI + nj; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, BB_MI * nj - (BB_MI + nj), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto round_done = [&]() {                    // my DMA pieces landed and my LDS writes completed; then everyone's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-    };
-
-    // ---- conv1: mid rows f = wave + 4j (row 13 is recomputed by the waves that own fewer rows; only f < 14 is stored)
-    int boff1[4], boff2[4];
+    // conv1: mid rows f = wave + 8j (waves 0 and 1 own three, the others two)
+    // conv2: output rows r = wave + 8j
+    int boff1[BB_J1], boff2[BB_J1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = min(wave + 4 * j, BB_MH - 1);
+    for (int j = 0; j < BB_J1; ++j) {
+        const int f = min(wave + BB_NW * j, BB_MH - 1);
         boff1[j] = f * BB_XROW + ln * BB_PS;
-        const int r = min(wave + 4 * j, BB_TH - 1), c = min(ln, BB_TW - 1);
+        const int r = min(wave + BB_NW * j, BB_TH - 1), c = min(ln, BB_TW - 1);
         boff2[j] = (r * BB_MW + c) * BB_PS;
     }
-    init_acc(p.b1);
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // my x-halo and W1c0 pieces landed
-    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");      // ... everyone's
-    stamp(2);
-    mma_chunk(s_w, s_x, boff1, BB_XROW, 0, 4);
-    stamp(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my W1c1 pieces landed
-    asm volatile("s_barrier" ::: "memory");      // everyone's did, and everyone finished reading W1c0
-    issue_w(rs_w2, s_w, 0);                      // conv2's first chunk lands under conv1's second
-    stamp(4);
-    mma_chunk(s_mid, s_x, boff1, BB_XROW, 1, 4);
-    stamp(5);
-    asm volatile("s_barrier" ::: "memory");      // everyone finished reading W1c1 (mid region) and the x halo
-    // residual = centre of the x halo -> registers, so that the halo region can take conv2's second chunk
-    bf16x4 rx[3][BB_MI];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int mi = 0; mi < BB_MI; ++mi)
-            rx[j][mi] = *reinterpret_cast<const bf16x4*>(s_x + (wave + 4 * j + 2) * BB_XROW + (ln + 2) * BB_PS + (mi * 16 + g * 4) * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = wave + 4 * j;
-        if (f < BB_MH) {
-            const int iy = oy0 - 1 + f, ix = ox0 - 1 + ln;
-            const bool inimg = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-#pragma unroll
-            for (int mi = 0; mi < BB_MI; ++mi) {
-                bf16x4 q;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = (__bf16)(inimg ? fmaxf(acc[mi][j][e], 0.f) : 0.f);
-                *reinterpret_cast<bf16x4*>(s_mid + (f * BB_MW + ln) * BB_PS + (mi * 16 + g * 4) * 2) = q;
-            }
-        }
-    }
-    // ---- conv2: output rows r = wave + 4j, j < 3
-    init_acc(p.b2);
-    stamp(6);
-    round_done();                                // W2c0 landed, mid is visible, everyone holds its residual
-    issue_w(rs_w2, s_x, 1);                      // conv2's second chunk lands in the halo region under conv2's first
-    stamp(7);
-    mma_chunk(s_w, s_mid, boff2, BB_MW * BB_PS, 0, 3);
-    stamp(8);
-    round_done();
-    stamp(9);
-    mma_chunk(s_x, s_mid, boff2, BB_MW * BB_PS, 1, 3);
-    stamp(10);
 
-    // ---- epilogue: + x, ReLU, bf16 store (4 channels = 8 bytes per lane and fragment)
-    __bf16* const out = reinterpret_cast<__bf16*>(p.out) + (size_t)n * p.H * p.W * 48;
+    // finished tile waiting for its stores: out-of-range offsets drop the lanes / rows outside the image
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    bf16x4 oq[BB_J2][BB_MI];
+    unsigned ovoff[BB_J2];
+    __amdgpu_buffer_rsrc_t rs_out = rs_w1;
+    bool pending = false;
+    auto flush = [&]() {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int r = wave + 4 * j, oy = oy0 + r, ox = ox0 + ln;
-        if (ln < BB_TW && oy < p.H && ox < p.W) {
+        for (int j = 0; j < BB_J2; ++j)
 #pragma unroll
-            for (int mi = 0; mi < BB_MI; ++mi) {
-                bf16x4 q;
+            for (int mi = 0; mi < BB_MI; ++mi)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oq[j][mi]), rs_out, ovoff[j], mi * 32, 0);
+    };
+
+    // tuning aid (SNCAL_BB_TRACE=<file>): per workgroup, clocks spent in [0] halo wait + opening barrier, [1] conv1, [2] residual read
+    // + mid write + barrier + next halo request, [3] conv2, [4] epilogue arithmetic, [5] tiles
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool tracing = p.trace != nullptr;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
+
+    for (; t < t_hi; t += per_xcd) {
+        if (tracing) tprev = __builtin_amdgcn_s_memtime();
+        const int n = tn, oy0 = ty * BB_TH, ox0 = tx * BB_TW;
+        tx += step_x; ty += step_y;                           // the next tile of this workgroup
+        if (tx >= p.tiles_x) { tx -= p.tiles_x; ++ty; }
+        while (ty >= p.tiles_y) { ty -= p.tiles_y; ++tn; }
+        init_acc(bias1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0), as a builtin so that hipcc's wait-count pass sees it: my pieces
+        asm volatile("" ::: "memory");                        // of this tile's x halo (first tile: and of the weights) have landed
+        asm volatile("s_barrier" ::: "memory");               // ... then everyone's, and everyone is past the old mid
+        if (pending && !(p.dbg & 1)) flush();                 // the previous tile's outputs drain under this tile's MFMAs
+        lap(0);
+        if (wave + BB_NW * (BB_J1 - 1) < BB_MH) {             // the first waves own one mid row more than the others
+            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1>{});
+            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1>{});
+        } else {
+            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1 - 1>{});
+            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1 - 1>{});
+        }
+        lap(1);
+        // residual = centre of the x halo -> registers: the halo region takes the NEXT tile's halo while conv2 runs
+        bf16x4 rx[BB_J2][BB_MI];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = (__bf16)fmaxf(acc[mi][j][e] + (float)rx[j][mi][e], 0.f);
-                *reinterpret_cast<bf16x4*>(out + ((size_t)oy * p.W + ox) * 48 + mi * 16 + g * 4) = q;
+        for (int j = 0; j < BB_J2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < BB_MI; ++mi)
+                rx[j][mi] = *reinterpret_cast<const bf16x4*>(s_x + (wave + BB_NW * j + 2) * BB_XROW + (ln + 2) * BB_PS + (mi * 16 + g * 4) * 2);
+#pragma unroll
+        for (int j = 0; j < BB_J1; ++j) {
+            const int f = wave + BB_NW * j;
+            if (f < BB_MH) {
+                const int iy = oy0 - 1 + f, ix = ox0 - 1 + ln;
+                const bool inimg = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+#pragma unroll
+                for (int mi = 0; mi < BB_MI; ++mi) {
+                    // relu(round(x)) == round(relu(x)) and a negative bf16 is a negative int16: ReLU on the packed pairs
+                    bf16x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = (__bf16)acc[mi][j][e];
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    const s16x4 z = {0, 0, 0, 0};
+                    const s16x4 r = __builtin_elementwise_max(__builtin_bit_cast(s16x4, q), z);
+                    *reinterpret_cast<s16x4*>(s_mid + (f * BB_MW + ln) * BB_PS + (mi * 16 + g * 4) * 2) = inimg ? r : z;
+                }
             }
         }
+        init_acc(bias2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my mid rows are written, my residual is in registers
+        asm volatile("s_barrier" ::: "memory");               // ... everyone's: mid is complete, nobody reads this x halo any more
+        if (!(p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);         // the next tile's halo lands under conv2
+        lap(2);
+        mma_chunk(s_w + 2 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 0, std::integral_constant<int, BB_J2>{});
+        mma_chunk(s_w + 3 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 1, std::integral_constant<int, BB_J2>{});
+
+        if ((p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);
+        lap(3);
+        // epilogue: + x, ReLU -> packed bf16 in registers (4 channels = 8 bytes per lane and fragment); stored by `flush`
+        rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < BB_J2; ++j) {
+            const int r = wave + BB_NW * j, oy = oy0 + r, ox = ox0 + ln;
+            ovoff[j] = (ln < BB_TW && oy < p.H && ox < p.W) ? (unsigned)(((oy * p.W + ox) * 48 + g * 4) * 2) : 0x80000000u;
+#pragma unroll
+            for (int mi = 0; mi < BB_MI; ++mi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oq[j][mi][e] = (__bf16)fmaxf(acc[mi][j][e] + (float)rx[j][mi][e], 0.f);
+        }
+        pending = true;
+        lap(4);
+        tsum[5] += 1;
     }
-    stamp(11);
+    if (pending) flush();
+    if (tracing && tid == 0)
+        for (int k = 0; k < 6; ++k) p.trace[(size_t)blockIdx.x * 8 + k] = tsum[k];
 }
 
 int launch_bblock48(const BBlockParams& p0, hipStream_t s) {
     BBlockParams p = p0;
     p.tiles_x = (p.W + BB_TW - 1) / BB_TW;
     p.tiles_y = (p.H + BB_TH - 1) / BB_TH;
-    static bool attr_done = false;
-    if (!attr_done) {
+    p.trace = nullptr;
+    static const int dbg = getenv("SNCAL_BB_DBG") ? atoi(getenv("SNCAL_BB_DBG")) : 0;
+    p.dbg = dbg;
+    static int n_wgs = 0;
+    if (!n_wgs) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bblock48_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_wgs = cus >= 8 ? cus / 8 * 8 : 256;                 // one workgroup per CU, a multiple of the 8 XCDs
     }
     static const char* trace_file = getenv("SNCAL_BB_TRACE");
-    const size_t nwg = (size_t)p.tiles_x * p.tiles_y * p.N;
-    p.trace = nullptr;
-    if (trace_file && hipMalloc(&p.trace, nwg * 128) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, nwg * 128, s);
-    SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)nwg), dim3(256), (size_t)BB_LDS, s, p);
+    if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * 64, s);
+    SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)n_wgs), dim3(64 * BB_NW), (size_t)BB_LDS, s, p);
     SNCAL_CHECK_LAUNCH();
     if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run
-        std::vector<unsigned long long> h(nwg * 16);
+        std::vector<unsigned long long> h((size_t)n_wgs * 8);
         (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), p.trace, nwg * 128, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h.data(), p.trace, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(p.trace);
         if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }

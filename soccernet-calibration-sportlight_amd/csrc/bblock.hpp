@@ -13,6 +13,7 @@ struct BBlockParams {
     const float* b2;
     int N, H, W;
     int tiles_x, tiles_y;   // filled by the launcher
+    int dbg;                // tuning aid (SNCAL_BB_DBG): 1 = drop the output stores, 2 = request the next halo after conv2 (timing only)
     unsigned long long* trace;   // tuning aid (SNCAL_BB_TRACE=<file>): 16 s_memtime stamps per workgroup, or null
 };
 

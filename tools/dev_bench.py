@@ -12,6 +12,8 @@ dev = torch.device('cuda:0')
 net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
 net.load_state_dict(seeded_weights('hrnet_w48', 1))
 x = torch.rand((B, 3, 540, 960), device=dev)
+if dtype == 'fp8':
+    net.calibrate_fp8(x[:8])
 for _ in range(1):
     net.forward(x, want_heat=False, decode_size=(540, 960))
 torch.cuda.synchronize()

@@ -92,28 +92,39 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
     // part of the address (pixel-in-row, k-group, left/right bounds) is the same for every row and the row rides in the scalar
     // offset -- no per-piece VALU work.  Slot 6, slots 126/127 and outside-image pixels read out of range -> zeros.
     const unsigned x_lds = (unsigned)(__UINTPTR_TYPE__)(lds_void*)s_x;      // LDS byte address of the halo region
-    auto issue_x = [&](int n, int oy0, int ox0) {
-        const i32x4_t rs_x = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_bytes, (unsigned)img_bytes);
-        unsigned xv[2];
+    unsigned xlane[2];                          // lane part of a piece's source offset, relative to the tile's first halo column
+    int xpx[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const unsigned slot = (unsigned)(k * 64 + lane);
-            const unsigned px = slot / 7u, cg = slot - px * 7u;
-            const int ix = ox0 - 2 + (int)px;
-            const bool ok = (cg < 6u) & (px < (unsigned)BB_XW) & ((unsigned)ix < (unsigned)p.W);
-            xv[k] = ok ? (unsigned)(ix * 96 + (int)cg * 16) : 0x80000000u;
-        }
-        for (int j = wave; j < 2 * BB_XH; j += BB_NW) {
-            const int hy = j >> 1, iy = oy0 - 2 + hy;
-            const bool rowok = (unsigned)iy < (unsigned)p.H;
-            const unsigned voff = rowok ? ((j & 1) ? xv[1] : xv[0]) : 0x80000000u;
-            dma_piece(rs_x, x_lds + (unsigned)j * 1024u, voff, rowok ? (unsigned)(iy * p.W * 96) : 0u);
-        }
+    for (int k = 0; k < 2; ++k) {
+        const unsigned slot = (unsigned)(k * 64 + lane);
+        const unsigned px = slot / 7u, cg = slot - px * 7u;
+        xpx[k] = (cg < 6u && px < (unsigned)BB_XW) ? (int)px : (1 << 20);      // padding slots: never inside the image
+        xlane[k] = px * 96u + cg * 16u;
+    }
+    i32x4_t xrs = raw_rsrc(p.x, (unsigned)img_bytes);       // state of the halo request in flight: image descriptor, lane offsets, first row
+    unsigned xv[2] = {0x80000000u, 0x80000000u};
+    int xoy = 0;
+    auto prepare_x = [&](int n, int oy0, int ox0) {
+        xrs = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_bytes, (unsigned)img_bytes);
+        xoy = oy0 - 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            xv[k] = (unsigned)(ox0 - 2 + xpx[k]) < (unsigned)p.W ? xlane[k] + (unsigned)((ox0 - 2) * 96) : 0x80000000u;
+    };
+    auto piece_x = [&](int j) {                  // piece j = half (j & 1) of halo row j >> 1
+        const int iy = xoy + (j >> 1);
+        const bool rowok = (unsigned)iy < (unsigned)p.H;
+        const unsigned voff = rowok ? ((j & 1) ? xv[1] : xv[0]) : 0x80000000u;
+        dma_piece(xrs, x_lds + (unsigned)j * 1024u, voff, rowok ? (unsigned)(iy * p.W * 96) : 0u);
+    };
+    auto issue_x = [&](int n, int oy0, int ox0, int first, int stride) {
+        prepare_x(n, oy0, ox0);
+        for (int j = first; j < 2 * BB_XH; j += stride) piece_x(j);
     };
     // tile coordinates: decoded once (scalar divisions), then advanced by the stride of the walk
     int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tn = t / (p.tiles_x * p.tiles_y);
     const int step_x = per_xcd % p.tiles_x, step_y = per_xcd / p.tiles_x;      // per_xcd tiles further = step_y rows and step_x columns
-    if (t < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);
+    if (t < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW, wave, BB_NW);
 
     // fragment offsets of k-step s within a 24-channel chunk: k-group kg = 4s + g -> (tap, cg); same order as pack_layer
     auto frag_off = [&](int s, int row_pitch, int chunk) -> int {
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
             for (int j = 0; j < BB_J1; ++j) acc[mi][j] = f32x4{bias[mi].x, bias[mi].y, bias[mi].z, bias[mi].w};
     };
     // one K-chunk of one conv: NJ pixel fragments per wave from the LDS image `src`
-    auto mma_chunk = [&](const char* wbuf, const char* src, const int (&boff)[BB_J1], int row_pitch, int chunk, auto nj_c) {
+    auto mma_chunk = [&](const char* wbuf, const char* src, const int (&boff)[BB_J1], int row_pitch, int chunk, auto nj_c, auto&& between) {
         constexpr int nj = decltype(nj_c)::value;
         // Operand fragments are read one k-step ahead of their MFMAs, and the reads are INTERLEAVED with the MFMAs (one ds_read
         // behind each of the first MFMAs, sched_group_barrier): this wave is alone on its SIMD, so while it issues a block of seven
@@ -173,6 +184,7 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
                 __builtin_amdgcn_sched_group_barrier(0x008, BB_MI * nj - (BB_MI + nj), 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            between(s);                         // hook between k-steps (the halo DMA pieces ride here)
         }
     };
     // conv1: mid rows f = wave + 8j (waves 0 and 1 own three, the others two)
@@ -200,12 +212,13 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oq[j][mi]), rs_out, ovoff[j], mi * 32, 0);
     };
 
-    // tuning aid (SNCAL_BB_TRACE=<file>): per workgroup, clocks spent in [0] halo wait + opening barrier, [1] conv1, [2] residual read
+    // tuning aid (SNCAL_BB_TRACE=<file>): per wave, clocks spent in [0] halo wait + opening barrier, [1] conv1, [2] residual read
     // + mid write + barrier + next halo request, [3] conv2, [4] epilogue arithmetic, [5] tiles
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool tracing = p.trace != nullptr;
     auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
 
+    auto nohook = [](int) {};
     for (; t < t_hi; t += per_xcd) {
         if (tracing) tprev = __builtin_amdgcn_s_memtime();
         const int n = tn, oy0 = ty * BB_TH, ox0 = tx * BB_TW;
@@ -216,14 +229,17 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0), as a builtin so that hipcc's wait-count pass sees it: my pieces
         asm volatile("" ::: "memory");                        // of this tile's x halo (first tile: and of the weights) have landed
         asm volatile("s_barrier" ::: "memory");               // ... then everyone's, and everyone is past the old mid
-        if (pending && !(p.dbg & 1)) flush();                 // the previous tile's outputs drain under this tile's MFMAs
         lap(0);
+        // the previous tile's outputs are stored between conv1's two K-chunks: behind the opening wait (whose vmcnt(0) they would
+        // otherwise prolong) and while the SIMD's other wave keeps the matrix pipe busy
         if (wave + BB_NW * (BB_J1 - 1) < BB_MH) {             // the first waves own one mid row more than the others
-            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1>{});
-            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1>{});
+            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1>{}, nohook);
+            if (pending && !(p.dbg & 1)) flush();
+            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1>{}, nohook);
         } else {
-            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1 - 1>{});
-            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1 - 1>{});
+            mma_chunk(s_w, s_x, boff1, BB_XROW, 0, std::integral_constant<int, BB_J1 - 1>{}, nohook);
+            if (pending && !(p.dbg & 1)) flush();
+            mma_chunk(s_w + BB_WBYTES, s_x, boff1, BB_XROW, 1, std::integral_constant<int, BB_J1 - 1>{}, nohook);
         }
         lap(1);
         // residual = centre of the x halo -> registers: the halo region takes the NEXT tile's halo while conv2 runs
@@ -254,13 +270,19 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
         }
         init_acc(bias2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my mid rows are written, my residual is in registers
-        asm volatile("s_barrier" ::: "memory");               // ... everyone's: mid is complete, nobody reads this x halo any more
-        if (!(p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);         // the next tile's halo lands under conv2
         lap(2);
-        mma_chunk(s_w + 2 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 0, std::integral_constant<int, BB_J2>{});
-        mma_chunk(s_w + 3 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 1, std::integral_constant<int, BB_J2>{});
+        asm volatile("s_barrier" ::: "memory");               // ... everyone's: mid is complete, nobody reads this x halo any more
+        lap(6);
+        // The next tile's halo lands under conv2.  The four YOUNGER waves (4..7) request it, ten pieces each, before their conv2: the
+        // matrix pipe favours the older wave of a SIMD, so waves 0..3 go straight into conv2 (per-wave phase trace, tools/bb_trace.py:
+        // requested by all eight waves it cost ~0.9k clk per tile between the barrier and the first conv2 MFMA; spread between the
+        // younger waves' k-steps the last pieces were requested too late and the next tile waited for them).
+        if (!(p.dbg & 2) && t + per_xcd < t_hi && wave >= BB_NW / 2) issue_x(tn, ty * BB_TH, tx * BB_TW, wave - BB_NW / 2, BB_NW / 2);
+        lap(7);
+        mma_chunk(s_w + 2 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 0, std::integral_constant<int, BB_J2>{}, nohook);
+        mma_chunk(s_w + 3 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 1, std::integral_constant<int, BB_J2>{}, nohook);
 
-        if ((p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW);
+        if ((p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW, wave, BB_NW);
         lap(3);
         // epilogue: + x, ReLU -> packed bf16 in registers (4 channels = 8 bytes per lane and fragment); stored by `flush`
         rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
@@ -278,8 +300,8 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
         tsum[5] += 1;
     }
     if (pending) flush();
-    if (tracing && tid == 0)
-        for (int k = 0; k < 6; ++k) p.trace[(size_t)blockIdx.x * 8 + k] = tsum[k];
+    if (tracing && lane == 0)
+        for (int k = 0; k < 8; ++k) p.trace[((size_t)blockIdx.x * BB_NW + wave) * 8 + k] = tsum[k];
 }
 
 int launch_bblock48(const BBlockParams& p0, hipStream_t s) {
@@ -298,11 +320,11 @@ int launch_bblock48(const BBlockParams& p0, hipStream_t s) {
         n_wgs = cus >= 8 ? cus / 8 * 8 : 256;                 // one workgroup per CU, a multiple of the 8 XCDs
     }
     static const char* trace_file = getenv("SNCAL_BB_TRACE");
-    if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * 64, s);
+    if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * BB_NW * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * BB_NW * 64, s);
     SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)n_wgs), dim3(64 * BB_NW), (size_t)BB_LDS, s, p);
     SNCAL_CHECK_LAUNCH();
     if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run
-        std::vector<unsigned long long> h((size_t)n_wgs * 8);
+        std::vector<unsigned long long> h((size_t)n_wgs * BB_NW * 8);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), p.trace, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(p.trace);

@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int HEAD_SRC_LDS = 3072;         // LDS bytes per source per q-slice (<= 48 source pixels x 64 B)
 constexpr int HEAD_MAX_DMA = 4;            // DMA instructions per wave per slice (<= 16 over the block)
 
-template <int M2, int NSRC, int KS1, int NP, int DB>
+template <int M2, int NSRC, int KS1, int NP, int DB, int GM>
 __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) void head_fused_kernel(const HeadParams p) {
     constexpr int HEAD_TH = 4 * NP;
     constexpr int OFF_W0 = NSRC * HEAD_SRC_LDS, OFF_W1 = OFF_W0 + 2 * KS1 * 1024, OFF_B0 = OFF_W1 + M2 * 1024;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
     unsigned lo00[NP][NSRC], ldx[NSRC], ldy[NP][NSRC];     // LDS byte offsets of the taps
     bf16x2 wtop[NP][NSRC], wbot[NP][NSRC];     // (w00, w01) and (w10, w11) as bf16 pairs for v_dot2c_f32_bf16
     bf16x8 bD[NP][KS1];
+    bf16x8 wint[NP];
 #pragma unroll
     for (int r = 0; r < NP; ++r) {
         const int y = oy0 + wave * NP + r;
@@ -153,6 +154,31 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
             lo00[r][s] = (unsigned)(s * HEAD_SRC_LDS + ((iy - by0[s]) * bw[s] + (ix - bx0[s])) * 64 + g * 16);
             ldx[s] = ix < p.Ws[s] - 1 ? 64u : 0u;
             ldy[r][s] = iy < p.Hs[s] - 1 ? (unsigned)(bw[s] * 64) : 0u;
+        }
+        if constexpr (GM) {
+            // gather-by-MFMA (two sources, boxes of <= 16 pixels): B fragment of the interpolation GEMM
+            //     h[ch, px] += sum_k t[ch, k] * wint[k, px],   k = 16 s + (pixel of source s's box),
+            // lane (px = ln, k-block g) holds the bf16 bilinear weights of box pixels 8 (g & 1) .. + 7 of source g >> 1 (zero
+            // where the pixel is not one of this output pixel's four taps).  Same bf16 weights as the VALU path's dot2 pairs.
+            float wq[4] = {0.f, 0.f, 0.f, 0.f};
+            int tq[4] = {-1, -1, -1, -1};
+#pragma unroll
+            for (int s2 = 0; s2 < NSRC; ++s2) {
+                const bool mine = (g >> 1) == s2;
+                const int t00 = (int)((lo00[r][s2] - (unsigned)(s2 * HEAD_SRC_LDS) - (unsigned)(g * 16)) >> 6);
+                const int t01 = t00 + (int)(ldx[s2] >> 6), t10 = t00 + (int)(ldy[r][s2] >> 6), t11 = t10 + (int)(ldx[s2] >> 6);
+                const float f00 = (float)wtop[r][s2][0], f01 = (float)wtop[r][s2][1], f10 = (float)wbot[r][s2][0], f11 = (float)wbot[r][s2][1];
+                tq[0] = mine ? t00 : tq[0]; tq[1] = mine ? t01 : tq[1]; tq[2] = mine ? t10 : tq[2]; tq[3] = mine ? t11 : tq[3];
+                wq[0] = mine ? f00 : wq[0]; wq[1] = mine ? f01 : wq[1]; wq[2] = mine ? f10 : wq[2]; wq[3] = mine ? f11 : wq[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int slot = 8 * (g & 1) + e;
+                float w = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w += slot == tq[k] ? wq[k] : 0.f;
+                wint[r][e] = (__bf16)w;
+            }
         }
         // stage-1 B fragments: K = [direct channels | upsampled narrow branches], 8 channels per lane and k-step.
         // Segment boundaries are multiples of 8 channels, so a lane's k-group lies in exactly one segment.
@@ -220,8 +246,25 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + OFF_W0 + ((f * KS1 + ks) * 64 + lane) * 16);
                     acc1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bD[r][ks], acc1[f], 0, 0, 0);
                 }
+            if constexpr (GM) {
+                // ---- gather as two more MFMAs: A fragment = the sources' box pixels of this slice, transposed on the fly -- lane
+                // (row m = ln -> hidden channel (m >> 2) * 8 + f * 4 + (m & 3), the stage-1 row order; k-block g) reads the 8 box
+                // pixels 8 (g & 1) .. + 7 of source g >> 1 for its channel: eight 2-byte LDS reads at a 64-byte stride.  64 VALU
+                // instructions (v_perm / v_dot2c) and eight ds_read_b128 per row and slice become 16 ds_read_u16 and 2 MFMAs.
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const unsigned short* tp = reinterpret_cast<const unsigned short*>(
+                        sb + (g >> 1) * HEAD_SRC_LDS + (8 * (g & 1)) * 64 + (((ln >> 2) * 8 + f * 4 + (ln & 3)) * 2));
+                    u16x8 t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = tp[e * 32];
+                    acc1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t), wint[r], acc1[f], 0, 0, 0);
+                }
+            }
             // ---- gather (from LDS) + ReLU: lane owns channels q*32 + g*8 .. +7 of its pixel ------------------
             float v[8] = {acc1[0][0], acc1[0][1], acc1[0][2], acc1[0][3], acc1[1][0], acc1[1][1], acc1[1][2], acc1[1][3]};
+            if constexpr (!GM) {
 #pragma unroll
             for (int s = 0; s < NSRC; ++s) {
                 const char* t = sb + lo00[r][s];
@@ -243,6 +286,7 @@ __global__ __launch_bounds__(256, DB ? (NP == 1 ? 3 : 2) : (NP == 1 ? 5 : 3)) vo
                     v[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(th, wtop[r][s], v[2 * pr + 1], false);
                     v[2 * pr + 1] = __builtin_amdgcn_fdot2_f32_bf16(bh, wbot[r][s], v[2 * pr + 1], false);
                 }
+            }
             }
             bf16x8 bH;
 #pragma unroll
@@ -276,8 +320,22 @@ void launch_one(const HeadParams& q, unsigned blocks, hipStream_t s) {
     // resident waves (25 KB of LDS, 92 VGPRs -> 5 per SIMD), not prefetch depth (measured 5.8 vs 6.9 ms)
     static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 0;     // tuning aid
     const size_t lds1 = (size_t)(NSRC * HEAD_SRC_LDS + (2 * KS1 + M2 + 1) * 1024);
-    if (db) SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-    else SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 0>), dim3(blocks), dim3(256), lds1, s, q);
+    // gather by MFMA: two gather sources whose worst-case boxes hold at most 16 pixels each (one DMA piece, K slots 16 s .. 16 s + 15)
+    static const int gm_env = getenv("SNCAL_HEAD_GM") ? atoi(getenv("SNCAL_HEAD_GM")) : 1;      // tuning aid: 0 = VALU gather
+    bool gm = NSRC == 2 && gm_env != 0;
+    for (int s2 = 0; s2 < NSRC && gm; ++s2) {
+        const int bh = (int)(q.sy[s2] * (4 * NP - 1)) + 3, bwid = (int)(q.sx[s2] * 15) + 3;
+        if (bh * bwid > 16) gm = false;
+    }
+    if constexpr (NSRC == 2) {
+        if (gm) {
+            if (db) SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 1, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+            else SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 0, 1>), dim3(blocks), dim3(256), lds1, s, q);
+            return;
+        }
+    }
+    if (db) SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+    else SNCAL_LAUNCH((head_fused_kernel<M2, NSRC, KS1, NP, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
 }
 
 template <int M2, int NP>

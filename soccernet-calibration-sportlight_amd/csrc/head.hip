@@ -355,6 +355,7 @@ int launch_m2(const HeadParams& q, unsigned blocks, hipStream_t s) {
 }
 
 int launch_head_fused(const HeadParams& p, int m2, hipStream_t s) {
+    if (launch_head32(p, s)) { SNCAL_CHECK_LAUNCH(); return SNCAL_OK; }      // the 32 x 32 x 16 version where it applies
     HeadParams q = p;
     if (p.nsrc < 2 || p.nsrc > 4) { set_error("fused head: %d gather sources", p.nsrc); return SNCAL_ERR_ARG; }
     static const int force_np = getenv("SNCAL_HEAD_NP") ? atoi(getenv("SNCAL_HEAD_NP")) : 0;     // tuning aid

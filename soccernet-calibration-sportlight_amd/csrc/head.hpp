@@ -18,6 +18,9 @@ struct HeadParams {
     const void* w0;                // stage-1 A fragments [NQ][2][ks1][64 lanes] x 16 B (rows permuted, BN scale folded)
     const float* bias0;            // [HP] folded BN shift of last_layer.0 (zero on the padding)
     const void* w1;                // stage-2 A fragments [NQ][M2][64 lanes] x 16 B
+    const void* w0_32;             // head32.hip: stage-1 A fragments of v_mfma_f32_32x32x16 [NQ][ks16][64 lanes] x 16 B (rows in tt_row_channel order), or null
+    const void* w1_32;             // head32.hip: stage-2 A fragments [NQ][ceil(LC / 32)][2][64 lanes] x 16 B (class rows in tt_row_channel order)
+    int ks16;                      // (Cd + sum Cf) / 16 when that is exact, else 0
     const float* bias1;            // [LC] bias of last_layer.3 (zero on the padding)
     int nsrc;
     const void* src[HEAD_MAX_SRC]; // t_i = W0_i . branch_i at native resolution, [N][Hs][Ws][HP] bf16
@@ -30,6 +33,12 @@ struct HeadParams {
     unsigned tiles_x_magic, tiles_y_magic;   // filled by the launcher: floor(2^32 / d) + 1
 };
 
+// head32.hip: row order of a 32-row block of A fragments.  The D registers of v_mfma_f32_32x32x16 give lane l rows 8 q + 4 (l >> 5) + j
+// (q, j = 0..3) of column l & 31; MFMA row r carries channel h32_row_channel(r) of the block, so that the registers 8 h .. 8 h + 7 of a
+// lane are the eight consecutive channels 16 h + 8 (l >> 5) + 0..7.
+constexpr int h32_row_channel(int r) { return 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3); }
+
 int launch_head_fused(const HeadParams& p, int m2, hipStream_t s);
+bool launch_head32(const HeadParams& p, hipStream_t s);      // head32.hip; false = does not apply, nothing launched
 
 }  // namespace sncal

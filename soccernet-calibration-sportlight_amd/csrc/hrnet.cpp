@@ -121,6 +121,8 @@ struct sncal_hrnet {
     std::vector<int> producer;                // per tensor: active op that writes it
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
+    void *d_hw0_32 = nullptr, *d_hw1_32 = nullptr;      // head32.hip packing (null when K1 is not a multiple of 16)
+    int head_ks16 = 0;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
     int cur_group = GRP_ALL;
     bool finalized = false;
@@ -636,7 +638,36 @@ int pack_head(sncal_hrnet& net) {
                 }
             }
     for (int c = 0; c < H1.cout; ++c) b1[c] = H1.shift[c];
-    for (void** q : {&net.d_hw0, &net.d_hw1}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    for (void** q : {&net.d_hw0, &net.d_hw1, &net.d_hw0_32, &net.d_hw1_32}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    net.head_ks16 = 0;
+    if (K1 % 16 == 0) {       // head32.hip: A fragments of v_mfma_f32_32x32x16_bf16 -- lane l holds row h32_row_channel(l & 31) of the 32-row
+        const int KS16 = K1 / 16, RB = (M2 * 16 + 31) / 32;                // block, k = 16 ks + 8 (l >> 5) + 0..7
+        std::vector<uint16_t> v0((size_t)NQ * KS16 * 64 * 8, 0), v1((size_t)NQ * RB * 2 * 64 * 8, 0);
+        for (int q = 0; q < NQ; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = h32_row_channel(lane & 31), kb = (lane >> 5) * 8;
+                const int ch = q * 32 + row;
+                for (int ks = 0; ks < KS16 && ch < H0.cout; ++ks) {
+                    uint16_t* dst = v0.data() + (((size_t)q * KS16 + ks) * 64 + lane) * 8;
+                    for (int e = 0; e < 8; ++e) dst[e] = f2bf(H0.w[(size_t)ch * H0.cin + coff + ks * 16 + kb + e] * H0.scale[ch]);
+                }
+                for (int rb = 0; rb < RB; ++rb)
+                    for (int h = 0; h < 2; ++h) {
+                        const int cls = rb * 32 + row;
+                        if (cls >= H1.cout) continue;
+                        uint16_t* dst = v1.data() + ((((size_t)q * RB + rb) * 2 + h) * 64 + lane) * 8;
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = q * 32 + h * 16 + kb + e;
+                            if (k < H1.cin) dst[e] = f2bf(H1.w[(size_t)cls * H1.cin + k] * H1.scale[cls]);
+                        }
+                    }
+            }
+        SNCAL_CHECK_HIP(hipMalloc(&net.d_hw0_32, v0.size() * 2));
+        SNCAL_CHECK_HIP(hipMalloc(&net.d_hw1_32, v1.size() * 2));
+        SNCAL_CHECK_HIP(hipMemcpy(net.d_hw0_32, v0.data(), v0.size() * 2, hipMemcpyHostToDevice));
+        SNCAL_CHECK_HIP(hipMemcpy(net.d_hw1_32, v1.data(), v1.size() * 2, hipMemcpyHostToDevice));
+        net.head_ks16 = KS16;
+    }
     if (net.d_hb0) { (void)hipFree(net.d_hb0); net.d_hb0 = nullptr; }
     if (net.d_hb1) { (void)hipFree(net.d_hb1); net.d_hb1 = nullptr; }
     SNCAL_CHECK_HIP(hipMalloc(&net.d_hw0, w0.size() * 2));
@@ -1182,7 +1213,7 @@ extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
-    for (void* q : {net->d_hw0, net->d_hw1, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
+    for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
 }
 
@@ -1516,6 +1547,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     memset(&hp, 0, sizeof(hp));
                     hp.direct = ws + td.offset; hp.Cd = td.C;
                     hp.w0 = net->d_hw0; hp.bias0 = net->d_hb0; hp.w1 = net->d_hw1; hp.bias1 = net->d_hb1;
+                    hp.w0_32 = net->d_hw0_32; hp.w1_32 = net->d_hw1_32; hp.ks16 = net->head_ks16;
                     hp.nsrc = op.head_nsrc;
                     for (int s2 = 0; s2 < op.head_nsrc; ++s2) {
                         const Tensor& ts = net->tensors[op.head_src[s2]];

@@ -10,6 +10,7 @@
     python -m sncal_amd.submit --img-dir DIR --model model.pth --save-dir OUT [--lines-file lines.pkl]
 """
 import argparse
+import warnings
 import os
 from typing import List, Optional
 
@@ -52,6 +53,7 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
     frames = [torch.empty((batch_size, H, W, 3), dtype=torch.uint8, device=net.device) for _ in range(2)]
     pending = []                                                                    # (names, records, event)
     written = 0
+    skipped = []                                                                    # frames the device decoder cannot take
 
     def drain(keep: int):
         nonlocal written
@@ -62,12 +64,40 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
             written += save_cameras(cams, names, save_dir)
 
     for k, i in enumerate(range(0, total, batch_size)):
-        names = img_names[i:i + batch_size]
-        blobs = []
-        for n in names:
+        names, blobs = [], []
+        for n in img_names[i:i + batch_size]:
             with open(os.path.join(img_dir, n), 'rb') as f:
-                blobs.append(f.read())
-        x = dec.decode(blobs, frames[k & 1][:len(blobs)])
+                blob = f.read()
+            # a file the device decoder does not handle (progressive, arithmetic-coded, CMYK, another size than the first frame's, damaged)
+            # is skipped with a warning and simply gets no camera file -- what the reference's loop does for a frame without a
+            # camera -- instead of ending the run (cv2.imread would decode some of these: decode them elsewhere and upload uint8 frames)
+            try:
+                fi = probe(blob)
+                if (fi['height'], fi['width']) != (H, W):
+                    raise _lib.SncalError(f"{fi['width']}x{fi['height']} where the run's frames are {W}x{H}")
+            except _lib.SncalError as e:
+                warnings.warn(f'{n}: skipped ({e})')
+                skipped.append(n)
+                continue
+            names.append(n)
+            blobs.append(blob)
+        if not blobs:
+            continue
+        try:
+            x = dec.decode(blobs, frames[k & 1][:len(blobs)])
+        except _lib.SncalError:                     # a stream that is damaged behind its headers: find it, drop it, decode the rest
+            keep = []
+            for n, blob in zip(names, blobs):
+                try:
+                    dec.decode([blob], frames[k & 1][:1])
+                    keep.append((n, blob))
+                except _lib.SncalError as e:
+                    warnings.warn(f'{n}: skipped ({e})')
+                    skipped.append(n)
+            if not keep:
+                continue
+            names, blobs = [n for n, _ in keep], [b for _, b in keep]
+            x = dec.decode(blobs, frames[k & 1][:len(blobs)])
         out = pipe.submit(x, names=names)
         ev = torch.cuda.Event()
         with torch.cuda.stream(pipe.solve_stream):
@@ -77,7 +107,7 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
     drain(0)
     pipe.join()
     dec.close()
-    return {'frames': total, 'written': written, 'completeness': written / total}
+    return {'frames': total, 'written': written, 'completeness': written / total, 'skipped': skipped}
 
 
 def main(argv=None):

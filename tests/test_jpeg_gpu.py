@@ -116,3 +116,31 @@ def test_directory_harness_runs_the_make_submit_loop(sncal, cuda, gold_dir, tmp_
     cams = cal.solve_batch(pred.cpu().numpy(), names)
     want = sorted('camera_' + n.replace('.jpg', '.json') for n, c in zip(names, cams) if c is not None)
     assert sorted(os.listdir(save_dir)) == want and res['written'] == len(want)
+
+
+def test_directory_harness_skips_files_the_decoder_cannot_take(sncal, cuda, gold_dir, tmp_path):
+    """A file that is not a JPEG and a frame of another size do not end the run (cv2.imread would not raise either, make_submit.py:62): they are
+    skipped with a warning, get no camera file and count against completeness."""
+    g, _ = _cases(gold_dir)
+    full = g['jpg.full'].tobytes()
+    small = g['jpg.48x64_420_q95_r0'].tobytes()
+    img_dir, save_dir = tmp_path / 'imgs', tmp_path / 'out'
+    img_dir.mkdir()
+    (img_dir / '00000.jpg').write_bytes(full)
+    (img_dir / '00001.jpg').write_bytes(b'\xff\xd8' + bytes(range(256)) * 4)     # not a JPEG stream behind the SOI marker
+    (img_dir / '00002.jpg').write_bytes(small)                          # 64x48 where the run's frames are 960x540
+    (img_dir / '00003.jpg').write_bytes(full)
+    cfg = hr.load_config('hrnet_w18')
+    ck = {'model_name': 'HRNetMetaModel',
+          'params': {'nn_module': {'hrnet_config': cfg, 'num_refinement_stages': 0, 'num_heatmaps': 58},
+                     'prediction_transform': {'size': [540, 960]}, 'device': 'cuda:0'},
+          'nn_state_dict': hr.seeded_state_dict(cfg, 3, 4.0)}
+    path = str(tmp_path / 'model.pth')
+    torch.save(ck, path)
+    model = sncal.load_model(path, loss=None, optimizer=None, device='cuda:0', dtype='fp32')
+    names = ['00000.jpg', '00001.jpg', '00002.jpg', '00003.jpg']
+    with pytest.warns(UserWarning, match='skipped'):
+        res = sncal.submit.make_submit(str(img_dir), model, sncal.submit.default_calibrator(), str(save_dir), batch_size=2,
+                                       img_names=names, decoder_threads=2)
+    assert res['frames'] == 4 and sorted(res['skipped']) == ['00001.jpg', '00002.jpg']
+    assert res['written'] <= 2 and all(f in ('camera_00000.json', 'camera_00003.json') for f in os.listdir(save_dir))

@@ -378,7 +378,7 @@ def main():
         traffic = None      # HBM bytes per launch from a separate rocprofv3 --pmc pass (tools/pmc_pass.sh -> profiles/pmc_traffic.json)
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-                traffic = json.load(f).get(dom['kernel'])
+                traffic = json.load(f).get(dom['kernel']) if args.size == '540p' else None      # the PMC pass ran the 960x540 shapes
         except OSError:
             pass
         peak = PEAK_TFLOPS['fp8' if 'fp8' in dom['kernel'] else 'bf16' if args.dtype == 'fp8' else args.dtype]

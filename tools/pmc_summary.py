@@ -11,7 +11,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         elif m: k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
         else:
             m2 = re.search(r'conv_(?:group_)?kernel<.*?(\d), (\d), (\d), (\d)>', k)
-            k = 'conv<NI%s,MI%s,G%s>' % m2.groups()[:3] if m2 else ('head_fused' if 'head_fused' in k else k[:48])
+            k = 'conv<NI%s,MI%s,G%s>' % m2.groups()[:3] if m2 else ('head_fused' if ('head_fused' in k or 'head32_kernel' in k) else 'bblock48_fused' if 'bblock48_kernel' in k else k[:48])
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         key = (r['Dispatch_Id'], k)
         if key not in seen: seen.add(key); cnt[k] += 1

@@ -6,6 +6,9 @@ f = json.load(open(os.path.join(d, 'FETCH_SIZE', 'summary.json'))); w = json.loa
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {'note': f'per-launch HBM bytes from PMC at sub-batch {batch} (profiles/{tag}_pmc_hbm_traffic.md)'}
 rows = []
+def label(k):
+    return 'head_fused' if 'head32_kernel' in k or 'head_fused' in k else 'bblock48_fused' if 'bblock48_kernel' in k else k
+f = {label(k): v for k, v in f.items()}; w = {label(k): v for k, v in w.items()}
 for k in f:
     if k not in w: continue
     fk, wk = f[k]['FETCH_SIZE'], w[k]['WRITE_SIZE']

@@ -28,7 +28,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int H32_SRC = 8 * 1024;          // per slice buffer: 4 waves x 2 sources x one 1 KB DMA piece (16 box pixels x 64 B)
 
-template <int RB, int KS, int DB>
+template <int RB, int KS, int DB, int HL>
 __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
     constexpr int OFF_W0 = H32_SRC, OFF_W1 = OFF_W0 + KS * 1024, OFF_B0 = OFF_W1 + RB * 2 * 1024, BUF = OFF_B0 + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -199,13 +199,18 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
         // ---- ReLU -> stage-2 B fragments (a register repack), stage 2: logits += W1[:, q-slice] . h -----------------------------------
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            bf16x8 bH;
+            bf16x8 bH, bL;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bH[e] = (__bf16)fmaxf(acc1[8 * h + e], 0.f);
+            for (int e = 0; e < 8; ++e) {
+                const float hv = fmaxf(acc1[8 * h + e], 0.f);
+                bH[e] = (__bf16)hv;
+                if constexpr (HL) bL[e] = (__bf16)(hv - (float)bH[e]);      // experiment (SNCAL_HEAD_HILO=1): hidden vector as bf16 hi + lo
+            }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + OFF_W1 + ((rb * 2 + h) * 64 + lane) * 16);
                 acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bH, acc2[rb], 0, 0, 0);
+                if constexpr (HL) acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bL, acc2[rb], 0, 0, 0);
             }
         }
     }
@@ -244,12 +249,16 @@ bool launch_head32(const HeadParams& p, hipStream_t s) {
     const int rb = (p.LC + 31) / 32;
     static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 1;
     const size_t lds1 = (size_t)(H32_SRC + (13 + rb * 2 + 1) * 1024);
+    // SNCAL_HEAD_HILO=1 (experiment): stage 2 multiplies the hidden vector as bf16 hi + bf16 lo (16 mantissa
+    // bits instead of 8) -- what "hidden -> logits in higher precision" buys is measured with tests/test_parity_gpu.py, DESIGN.md 8
+    static const int hilo = getenv("SNCAL_HEAD_HILO") ? atoi(getenv("SNCAL_HEAD_HILO")) : 0;
     if (rb == 2) {
-        if (db) SNCAL_LAUNCH((head32_kernel<2, 13, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-        else SNCAL_LAUNCH((head32_kernel<2, 13, 0>), dim3(blocks), dim3(256), lds1, s, q);
+        if (hilo) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else if (db) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else SNCAL_LAUNCH((head32_kernel<2, 13, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
     } else {
-        if (db) SNCAL_LAUNCH((head32_kernel<1, 13, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-        else SNCAL_LAUNCH((head32_kernel<1, 13, 0>), dim3(blocks), dim3(256), lds1, s, q);
+        if (db) SNCAL_LAUNCH((head32_kernel<1, 13, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else SNCAL_LAUNCH((head32_kernel<1, 13, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
     }
     return true;
 }

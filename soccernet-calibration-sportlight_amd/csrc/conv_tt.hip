@@ -376,16 +376,21 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
             for (int t = 0; t < NT; ++t) {
                 const int cur = t & 1;
                 if (t == NT - 2) near_end();
-                if (t + 1 < NT) {
-                    load_frags(t + 1, cur ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);             // ... and keep the reads ABOVE this step's MFMAs: hipcc otherwise sinks
-                }                                                  // them below five of the six (register reuse) and every step waits for LDS
+                if (t + 1 < NT) load_frags(t + 1, cur ^ 1);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int jr = 0; jr < NB; ++jr)
                         acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mb], b[cur][jr], acc[mb][jr], 0, 0, 0);
-                if (t + 1 < NT) __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the next step's MFMAs
+                if (t + 1 < NT) {                                  // one fragment read behind each of the first five MFMAs of the step
+#pragma unroll
+                    for (int i = 0; i < MB + NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MB * NB - (MB + NB), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     };

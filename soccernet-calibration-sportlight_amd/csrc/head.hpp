@@ -31,6 +31,7 @@ struct HeadParams {
     int HP, NQ, LC;                // padded hidden width (800), HP/32, padded class count (M2*16)
     int tiles_x, tiles_y;          // filled by the launcher
     unsigned tiles_x_magic, tiles_y_magic;   // filled by the launcher: floor(2^32 / d) + 1
+    unsigned long long* trace;     // head32.hip tuning aid (SNCAL_HEAD_TRACE=<file>): 8 phase sums per workgroup, or null
 };
 
 // head32.hip: row order of a 32-row block of A fragments.  The D registers of v_mfma_f32_32x32x16 give lane l rows 8 q + 4 (l >> 5) + j

@@ -16,7 +16,9 @@
 // of its pixel -- exactly the 8 k-values that lane must supply to stage 2's K = 16 step h.
 #include "common.hpp"
 #include "head.hpp"
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #pragma clang fp contract(fast)
 
@@ -29,11 +31,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int H32_SRC = 8 * 1024;          // per slice buffer: 4 waves x 2 sources x one 1 KB DMA piece (16 box pixels x 64 B)
 
 template <int RB, int KS, int DB, int HL>
-__global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
+__global__ __launch_bounds__(256, DB ? 3 : 4) void head32_kernel(const HeadParams p) {
     constexpr int OFF_W0 = H32_SRC, OFF_W1 = OFF_W0 + KS * 1024, OFF_B0 = OFF_W1 + RB * 2 * 1024, BUF = OFF_B0 + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long t_begin = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     int tile = blockIdx.x;
     const unsigned q1 = p.tiles_x == 1 ? (unsigned)tile : __umulhi((unsigned)tile, p.tiles_x_magic);
     const int tx = tile - (int)q1 * p.tiles_x;
@@ -160,6 +163,11 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
         for (int e = 0; e < 16; ++e) acc2[rb][e] = 0.f;
     const int tch = h32_row_channel(l31);         // hidden channel (within a slice) of this lane's row of a transposed box fragment
 
+    // tuning aid: clocks of wave 0 in [0] wait + barrier, [1] next slice requested, [2] stage 1, [3] gather, [4] ReLU + stage 2, [5] prologue
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool tracing = p.trace != nullptr;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
+    if (tracing) { tprev = t_begin; lap(5); }
     for (int q = 0; q < p.NQ; ++q) {
         const int buf = DB ? (q & 1) : 0;
         if (!DB && q > 0) {
@@ -168,7 +176,9 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of slice q landed
         asm volatile("s_barrier" ::: "memory");              // everyone's did; everyone is done with slice q-1
+        lap(0);
         if (DB && q + 1 < p.NQ) issue_slice(q + 1, buf ^ 1);       // lands while slice q is consumed
+        lap(1);
         const char* const sb = smem + buf * BUF;
         // ---- stage 1: 32 hidden channels x 32 pixels; accumulator registers 8 h .. 8 h + 7 = channels 16 h + 8 hi + 0..7, started at
         // the folded-BN shift
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + OFF_W0 + (ks * 64 + lane) * 16);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bD[ks], acc1, 0, 0, 0);
         }
+        lap(2);
         // ---- gather: one more MFMA per wide branch.  A fragment = the box pixels of this slice, transposed on the fly: lane (row l31 ->
         // channel h32_row_channel(l31), k-block hi) reads box pixels 8 hi .. 8 hi + 7 for its channel (eight 2-byte reads, 64-byte stride)
         typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
             for (int e = 0; e < 8; ++e) t[e] = tp[e * 32];
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t), wint[s], acc1, 0, 0, 0);
         }
+        lap(3);
         // ---- ReLU -> stage-2 B fragments (a register repack), stage 2: logits += W1[:, q-slice] . h -----------------------------------
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -213,7 +225,10 @@ __global__ __launch_bounds__(256, 3) void head32_kernel(const HeadParams p) {
                 if constexpr (HL) acc2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bL, acc2[rb], 0, 0, 0);
             }
         }
+        lap(4);
     }
+    if (tracing && threadIdx.x == 0 && blockIdx.x % 97 == 0)
+        for (int k = 0; k < 6; ++k) p.trace[(size_t)(blockIdx.x / 97) * 8 + k] = tsum[k];
     // ---- logits (+ conv bias) -> fp32 NHWC [P][LC]; registers 8 h .. 8 h + 7 of block rb = classes 32 rb + 16 h + 8 hi + 0..7 ----------
     if (valid) {
 #pragma unroll
@@ -247,7 +262,13 @@ bool launch_head32(const HeadParams& p, hipStream_t s) {
     q.tiles_y_magic = q.tiles_y <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_y + 1u;
     const unsigned blocks = (unsigned)(q.tiles_x * q.tiles_y * p.N);
     const int rb = (p.LC + 31) / 32;
-    static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 1;
+    static const char* trace_file = getenv("SNCAL_HEAD_TRACE");
+    const size_t n_tr = (size_t)(blocks / 97 + 1) * 8;
+    q.trace = nullptr;
+    if (trace_file && hipMalloc(&q.trace, n_tr * 8) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, n_tr * 8, s);
+    // single-buffered slices by default: 26 KB of LDS and 128 VGPRs let FOUR workgroups share a CU, and a workgroup's prologue (boxes,
+    // interpolation weights, 13 B fragments: 22 % of its life) and slice waits hide under the others -- 3.8 ms against 4.2 ms double-buffered at three
+    static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 0;
     const size_t lds1 = (size_t)(H32_SRC + (13 + rb * 2 + 1) * 1024);
     // SNCAL_HEAD_HILO=1 (experiment): stage 2 multiplies the hidden vector as bf16 hi + bf16 lo (16 mantissa
     // bits instead of 8) -- what "hidden -> logits in higher precision" buys is measured with tests/test_parity_gpu.py, DESIGN.md 8
@@ -259,6 +280,13 @@ bool launch_head32(const HeadParams& p, hipStream_t s) {
     } else {
         if (db) SNCAL_LAUNCH((head32_kernel<1, 13, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
         else SNCAL_LAUNCH((head32_kernel<1, 13, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
+    }
+    if (q.trace) {
+        std::vector<unsigned long long> h(n_tr);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), q.trace, n_tr * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_tr, f); fclose(f); }
     }
     return true;
 }

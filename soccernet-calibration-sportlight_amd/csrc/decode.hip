@@ -206,14 +206,18 @@ __global__ __launch_bounds__(256) void logsoftmax_rowcol_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void kp_finish_kernel(const float* __restrict__ rowmax, const float* __restrict__ colpart, int nstrips,
+__global__ __launch_bounds__(256) void kp_finish_kernel(const float* __restrict__ rowmax, int nrparts, const float* __restrict__ colpart, int nstrips,
                                                         int C1, int h, int w, int img_h, int img_w, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_row = smem;                          // [h]
     float* s_col = smem + h;                      // [w]
     float* s_scr = s_col + w;                     // [4]
     const int plane = blockIdx.x, b = plane / C1, c = plane - b * C1;
-    for (int y = threadIdx.x; y < h; y += 256) s_row[y] = rowmax[(size_t)plane * h + y];
+    for (int y = threadIdx.x; y < h; y += 256) {          // row maxima: nrparts partial maxima per row (1: final values)
+        float m = -INFINITY;
+        for (int k = 0; k < nrparts; ++k) m = fmaxf(m, rowmax[((size_t)plane * h + y) * nrparts + k]);
+        s_row[y] = m;
+    }
     for (int x = threadIdx.x; x < w; x += 256) {
         float m = -INFINITY;
         for (int s = 0; s < nstrips; ++s) m = fmaxf(m, colpart[(((size_t)b * nstrips + s) * C1 + c) * w + x]);
@@ -305,8 +309,18 @@ int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int
     float* colpart = scratch + (size_t)B * (C - 1) * h;
     SNCAL_LAUNCH_FIRST(logsoftmax_rowcol_kernel, dim3(nstrips, B), dim3(256), 0, s, logits, cstride, C, h, w, rowmax, colpart, nstrips);
     SNCAL_CHECK_LAUNCH();
-    SNCAL_LAUNCH_LAST(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowmax, colpart, nstrips,
+    SNCAL_LAUNCH_LAST(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowmax, 1, colpart, nstrips,
                        C - 1, h, w, img_h, img_w, kpts);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
+// second half of the decode when the head kernel itself produced the maxima (head32.hip, decode-fused form): row maxima in `row_parts`
+// partials per row [B][C-1][h][row_parts], column maxima in `col_parts` strips [B][col_parts][C-1][w]
+int launch_kp_finish(const float* rowpart, int row_parts, const float* colpart, int col_parts, int C, int B, int h, int w, int img_h, int img_w,
+                     float* kpts, hipStream_t s) {
+    SNCAL_LAUNCH(kp_finish_kernel, dim3(B * (C - 1)), dim3(256), (size_t)(h + w + 4) * sizeof(float), s, rowpart, row_parts, colpart, col_parts,
+                 C - 1, h, w, img_h, img_w, kpts);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

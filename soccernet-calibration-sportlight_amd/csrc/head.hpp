@@ -27,6 +27,11 @@ struct HeadParams {
     int Hs[HEAD_MAX_SRC], Ws[HEAD_MAX_SRC];
     float sy[HEAD_MAX_SRC], sx[HEAD_MAX_SRC];
     float* logits;                 // [N][H][W][LC] fp32
+    // head32.hip, decode-fused form (nobody wants the heatmap): log-softmax and the tile's row / column maxima in the epilogue, no logits
+    // written.  dec_row [N][C-1][H][tiles_x] and dec_col [N][tiles_y][C-1][W] feed kp_finish (decode.hip); both null = write logits
+    float* dec_row;
+    float* dec_col;
+    int dec_C;                     // real class count incl. background (58)
     int N, H, W;
     int HP, NQ, LC;                // padded hidden width (800), HP/32, padded class count (M2*16)
     int tiles_x, tiles_y;          // filled by the launcher
@@ -41,5 +46,8 @@ constexpr int h32_row_channel(int r) { return 16 * (r >> 4) + 8 * ((r >> 2) & 1)
 
 int launch_head_fused(const HeadParams& p, int m2, hipStream_t s);
 bool launch_head32(const HeadParams& p, hipStream_t s);      // head32.hip; false = does not apply, nothing launched
+bool head32_applies(const HeadParams& p);                  // the same test without launching
+size_t head32_decode_scratch(int B, int C, int h, int w);   // bytes of dec_row + dec_col
+void head32_decode_parts(int h, int w, int* row_parts, int* col_parts);
 
 }  // namespace sncal

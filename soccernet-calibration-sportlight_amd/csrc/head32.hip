@@ -16,6 +16,7 @@
 // of its pixel -- exactly the 8 k-values that lane must supply to stage 2's K = 16 step h.
 #include "common.hpp"
 #include "head.hpp"
+#include "softmax_px.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -30,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int H32_SRC = 8 * 1024;          // per slice buffer: 4 waves x 2 sources x one 1 KB DMA piece (16 box pixels x 64 B)
 
-template <int RB, int KS, int DB, int HL>
+template <int RB, int KS, int DB, int HL, int DEC>
 __global__ __launch_bounds__(256, DB ? 3 : 4) void head32_kernel(const HeadParams p) {
     constexpr int OFF_W0 = H32_SRC, OFF_W1 = OFF_W0 + KS * 1024, OFF_B0 = OFF_W1 + RB * 2 * 1024, BUF = OFF_B0 + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,6 +230,52 @@ __global__ __launch_bounds__(256, DB ? 3 : 4) void head32_kernel(const HeadParam
     }
     if (tracing && threadIdx.x == 0 && blockIdx.x % 97 == 0)
         for (int k = 0; k < 6; ++k) p.trace[(size_t)(blockIdx.x / 97) * 8 + k] = tsum[k];
+    if constexpr (DEC) {
+        // ---- decode-fused epilogue: log-softmax per pixel (softmax_px.hpp: bit-identical to the softmax kernels), then the tile's maxima
+        // per class -- over its 32 columns for every row, over its 4 rows for every column -- which is all the keypoint decode needs
+        // (transforms.py:230-238: argmax of the column maxima / row maxima).  The (N,58,h,w) log-probabilities and the logits are never
+        // written: 2 x 2.1 GB per 64 frames less HBM traffic and one kernel less.
+        static_assert(!DEC || RB == 2, "the two-lane softmax holds 64 channel slots per pixel");
+        float v[32], r[32];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = rb * 32 + 16 * h + 8 * hi;
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias1 + c), b1 = *reinterpret_cast<const float4*>(p.bias1 + c + 4);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * (2 * rb + h) + e] = c + e < p.dec_C ? acc2[rb][8 * h + e] + bb[e] : -INFINITY;
+            }
+        logsoftmax_px32x2(v, hi, p.dec_C, r);
+        // [row of the tile][class][pixel] in LDS (the slice buffers are free: everyone is past the last slice)
+        asm volatile("s_barrier" ::: "memory");
+        float* const s_lp = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_lp[(wave * 64 + 16 * k + 8 * hi + e) * 32 + l31] = valid ? r[8 * k + e] : -INFINITY;
+        __syncthreads();
+        const int C1 = p.dec_C - 1, t = threadIdx.x;
+        {   // row maxima: thread -> (row t >> 6, class t & 63)
+            const int rw = t >> 6, c = t & 63, yy = oy0 + rw;
+            if (c < C1 && yy < p.H) {
+                const float4* q = reinterpret_cast<const float4*>(s_lp + (rw * 64 + c) * 32);
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float4 u = q[i]; m = fmaxf(m, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w))); }
+                p.dec_row[(((size_t)n * C1 + c) * p.H + yy) * p.tiles_x + tx] = m;
+            }
+        }
+        for (int id = t; id < C1 * 32; id += 256) {      // column maxima: (class id >> 5, column id & 31)
+            const int c = id >> 5, xx = id & 31;
+            if (ox0 + xx < p.W) {
+                const float m = fmaxf(fmaxf(s_lp[(0 * 64 + c) * 32 + xx], s_lp[(1 * 64 + c) * 32 + xx]), fmaxf(s_lp[(2 * 64 + c) * 32 + xx], s_lp[(3 * 64 + c) * 32 + xx]));
+                p.dec_col[(((size_t)n * p.tiles_y + ty) * C1 + c) * p.W + ox0 + xx] = m;
+            }
+        }
+        return;
+    }
     // ---- logits (+ conv bias) -> fp32 NHWC [P][LC]; registers 8 h .. 8 h + 7 of block rb = classes 32 rb + 16 h + 8 hi + 0..7 ----------
     if (valid) {
 #pragma unroll
@@ -248,13 +295,35 @@ __global__ __launch_bounds__(256, DB ? 3 : 4) void head32_kernel(const HeadParam
 
 // applies when: two gather sources whose per-wave boxes (one output row x 32 columns) hold at most 16 pixels, K1 = ks16 * 16 with an
 // instantiated depth, LC a multiple of 8 and at most 64.  Returns false (nothing launched) otherwise: the 16 x 16 x 32 kernel runs.
-bool launch_head32(const HeadParams& p, hipStream_t s) {
+static bool finish_trace(const HeadParams& q, size_t n_tr, const char* trace_file, hipStream_t s) {
+    if (q.trace) {
+        std::vector<unsigned long long> h(n_tr);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), q.trace, n_tr * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_tr, f); fclose(f); }
+    }
+    return true;
+}
+
+bool head32_applies(const HeadParams& p) {
     static const int enabled = getenv("SNCAL_HEAD32") ? atoi(getenv("SNCAL_HEAD32")) : 1;      // tuning aid: 0 = head.hip
     if (!enabled || p.nsrc != 2 || !p.w0_32 || !p.w1_32 || p.ks16 != 13 || p.LC > 64 || p.LC % 8) return false;
     for (int s2 = 0; s2 < 2; ++s2) {
         const int bwid = (int)(p.sx[s2] * 31) + 3;                 // worst-case box: 2 rows x bwid columns
         if (2 * bwid > 16) return false;
     }
+    return true;
+}
+void head32_decode_parts(int h, int w, int* row_parts, int* col_parts) { *row_parts = (w + 31) / 32; *col_parts = (h + 3) / 4; }
+size_t head32_decode_scratch(int B, int C, int h, int w) {
+    int rp, cp;
+    head32_decode_parts(h, w, &rp, &cp);
+    return ((size_t)B * (C - 1) * h * rp + (size_t)B * cp * (C - 1) * w) * sizeof(float);
+}
+
+bool launch_head32(const HeadParams& p, hipStream_t s) {
+    if (!head32_applies(p)) return false;
     HeadParams q = p;
     q.tiles_x = (p.W + 31) / 32;
     q.tiles_y = (p.H + 3) / 4;
@@ -270,25 +339,22 @@ bool launch_head32(const HeadParams& p, hipStream_t s) {
     // interpolation weights, 13 B fragments: 22 % of its life) and slice waits hide under the others -- 3.8 ms against 4.2 ms double-buffered at three
     static const int db = getenv("SNCAL_HEAD_DB") ? atoi(getenv("SNCAL_HEAD_DB")) : 0;
     const size_t lds1 = (size_t)(H32_SRC + (13 + rb * 2 + 1) * 1024);
+    if (p.dec_row && p.dec_col && rb == 2) {       // decode-fused form: 32 KB of LDS for the tile's log-probabilities
+        SNCAL_LAUNCH((head32_kernel<2, 13, 0, 0, 1>), dim3(blocks), dim3(256), (size_t)32 * 1024, s, q);
+        return finish_trace(q, n_tr, trace_file, s);
+    }
     // SNCAL_HEAD_HILO=1 (experiment): stage 2 multiplies the hidden vector as bf16 hi + bf16 lo (16 mantissa
     // bits instead of 8) -- what "hidden -> logits in higher precision" buys is measured with tests/test_parity_gpu.py, DESIGN.md 8
     static const int hilo = getenv("SNCAL_HEAD_HILO") ? atoi(getenv("SNCAL_HEAD_HILO")) : 0;
     if (rb == 2) {
-        if (hilo) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 1>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-        else if (db) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-        else SNCAL_LAUNCH((head32_kernel<2, 13, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
+        if (hilo) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else if (db) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 0, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else SNCAL_LAUNCH((head32_kernel<2, 13, 0, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
     } else {
-        if (db) SNCAL_LAUNCH((head32_kernel<1, 13, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
-        else SNCAL_LAUNCH((head32_kernel<1, 13, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
+        if (db) SNCAL_LAUNCH((head32_kernel<1, 13, 1, 0, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);
+        else SNCAL_LAUNCH((head32_kernel<1, 13, 0, 0, 0>), dim3(blocks), dim3(256), lds1, s, q);
     }
-    if (q.trace) {
-        std::vector<unsigned long long> h(n_tr);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), q.trace, n_tr * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(q.trace);
-        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_tr, f); fclose(f); }
-    }
-    return true;
+    return finish_trace(q, n_tr, trace_file, s);
 }
 
 }  // namespace sncal

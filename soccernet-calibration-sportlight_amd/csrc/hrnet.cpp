@@ -1444,6 +1444,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
         const int sb = std::min(SB, B - b0);
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);
         bool skip_next = false, decoded = false;
+        bool head_decoded = false;       // the head kernel produced the decode's partial maxima instead of logits
         int skip_group = 0;                                  // remaining members of a launch group that already ran
         for (size_t oi = 0; oi < net->ops.size(); ++oi) {
             const Op& op = net->ops[oi];
@@ -1528,6 +1529,16 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     // nobody wants the heatmap (predict() / the pipeline): log-softmax and the keypoint decode run fused and the
                     // (B,C,h,w) tensor is never written; its workspace slot serves as the (much smaller) scratch
                     static const bool fuse_decode = !(getenv("SNCAL_FUSE_DECODE") && atoi(getenv("SNCAL_FUSE_DECODE")) == 0);
+                    if (head_decoded) {        // head32.hip already holds log-softmax + the tiles' maxima: the decode's second half only
+                        int rp, cp;
+                        head32_decode_parts(tl.H, tl.W, &rp, &cp);
+                        const float* parts = reinterpret_cast<const float*>(ws + tl.offset);        // the logits tensor's slot holds them
+                        rc = launch_kp_finish(parts, rp, parts + (size_t)sb * (C - 1) * tl.H * rp, cp, C, sb, tl.H, tl.W, img_h, img_w,
+                                              d_kpts + (size_t)b0 * (C - 1) * 3, stream);
+                        decoded = true;
+                        if (net->profiling) { net->last_kernel = "kp_finish"; net->last_bytes = (double)head32_decode_scratch(sb, C, tl.H, tl.W); }
+                        break;
+                    }
                     if (fuse_decode && !d_heat && d_kpts && !net->desc.head_softmax &&
                         logsoftmax_decode_scratch(sb, C, tl.H, tl.W) <= (size_t)sb * C * th.H * th.W * sizeof(float)) {
                         rc = launch_logsoftmax_decode(reinterpret_cast<const float*>(ws + tl.offset), tl.C, C, sb, tl.H, tl.W, img_h, img_w,
@@ -1564,6 +1575,20 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     }
                     hp.logits = reinterpret_cast<float*>(ws + to.offset);
                     hp.N = sb; hp.H = to.H; hp.W = to.W; hp.HP = net->head_hp; hp.NQ = net->head_hp / 32; hp.LC = to.C;
+                    {   // nobody wants the heatmap: log-softmax and the decode's maxima inside the head kernel (head32.hip), neither logits nor
+                        // log-probabilities are written; the logits tensor's own workspace slot (alive from here to the softmax op) holds the
+                        // partial maxima instead
+                        static const bool fuse_dec = !(getenv("SNCAL_FUSE_DECODE") && atoi(getenv("SNCAL_FUSE_DECODE")) == 0) &&
+                                                     !(getenv("SNCAL_HEAD_DECODE") && atoi(getenv("SNCAL_HEAD_DECODE")) == 0);
+                        head_decoded = false;
+                        if (fuse_dec && !d_heat && d_kpts && !net->desc.head_softmax && C > 32 && C <= 64 && head32_applies(hp) &&
+                            head32_decode_scratch(sb, C, to.H, to.W) <= to.bytes && th.H == to.H && th.W == to.W) {
+                            int rp, cp;
+                            head32_decode_parts(to.H, to.W, &rp, &cp);
+                            hp.dec_row = hp.logits; hp.dec_col = hp.logits + (size_t)sb * (C - 1) * to.H * rp; hp.dec_C = C;
+                            head_decoded = true;
+                        }
+                    }
                     rc = launch_head_fused(hp, net->head_m2, stream);
                     if (net->profiling) {
                         net->last_kernel = "head_fused";

@@ -28,6 +28,8 @@ int launch_softmax_nchw(const float* logits, int cstride, int C, size_t npix_tot
 // fused log-softmax + D1 keypoint decode (decode.hip): NHWC fp32 logits -> (B,C-1,3) keypoints without the heatmap;
 // `scratch` holds logsoftmax_decode_scratch() bytes
 size_t logsoftmax_decode_scratch(int B, int C, int h, int w);
+int launch_kp_finish(const float* rowpart, int row_parts, const float* colpart, int col_parts, int C, int B, int h, int w, int img_h, int img_w,
+                     float* kpts, hipStream_t s);
 int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int h, int w, int img_h, int img_w, float* scratch,
                              float* kpts, hipStream_t s);
 

@@ -35,4 +35,31 @@ __device__ __forceinline__ void load_px16(const float* __restrict__ logits, size
     }
 }
 
+// The same per-pixel log-softmax for the accumulator layout of head32.hip: TWO lanes (l and l ^ 32, hi = l >> 5) hold one pixel, 32
+// channels each -- v[8 * k + e] = channel 16 * k + 8 * hi + e, k = 0..3 (k = quarter q of softmax_px16).  Bit-identical to
+// softmax_px16(log_mode = 1): the maximum is exact in any grouping; quarter k's sum runs 0 + e_0 + ... + e_15 in channel order, i.e.
+// through the hi = 0 lane's eight terms and on through the hi = 1 lane's; the four quarter sums combine as (s0 + s1) + (s2 + s3).
+#pragma clang fp contract(off)
+__device__ __forceinline__ void logsoftmax_px32x2(const float (&v)[32], int hi, int C, float (&r)[32]) {
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < 32; ++j) m = fmaxf(m, v[j]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float e[32], part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[8 * k + j] = (16 * k + 8 * hi + j < C) ? expf(v[8 * k + j] - m) : 0.f;
+        const float lower = __shfl_xor(0.f + e[8 * k] + e[8 * k + 1] + e[8 * k + 2] + e[8 * k + 3] + e[8 * k + 4] + e[8 * k + 5] + e[8 * k + 6] + e[8 * k + 7], 32, 64);
+        // hi = 1: continue the partner's partial sum with this lane's eight terms (hi = 0 computes a value nobody uses)
+        part[k] = lower + e[8 * k] + e[8 * k + 1] + e[8 * k + 2] + e[8 * k + 3] + e[8 * k + 4] + e[8 * k + 5] + e[8 * k + 6] + e[8 * k + 7];
+    }
+    float ssum = (part[0] + part[1]) + (part[2] + part[3]);
+    const float other = __shfl_xor(ssum, 32, 64);
+    ssum = hi ? ssum : other;                       // the hi = 1 lane holds the pixel's sum
+    const float ls = logf(ssum);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) r[j] = (v[j] - m) - ls;
+}
+
 }  // namespace sncal

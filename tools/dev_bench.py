@@ -23,7 +23,7 @@ for _ in range(steps):
     net.forward(x, want_heat=False, decode_size=(540, 960))
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
-print(f'B={B} {dtype} subbatch={os.environ.get("SNCAL_SUBBATCH", "8")}: {dt*1e3:.1f} ms/step, {B/dt:.1f} frames/s, {B/dt*507.82e9/1e12:.1f} TFLOP/s (reference-formulation flops)')
+print(f'B={B} {dtype} subbatch={os.environ.get("SNCAL_SUBBATCH", "64")}: {dt*1e3:.1f} ms/step, {B/dt:.1f} frames/s, {B/dt*507.82e9/1e12:.1f} TFLOP/s (reference-formulation flops)')
 
 prof = sorted(net.get_profile(), key=lambda p: -p['ms'])
 tot = sum(p['ms'] for p in prof)

@@ -255,7 +255,8 @@ int sncal_evaluate_cameras_detail(const sncal_camera* d_cams, int B, const doubl
  * is the input of sncal_hrnet_forward_u8.
  * Supported: 8-bit sequential DCT (SOF0/SOF1), Huffman, one interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
  * restart intervals.  Progressive / arithmetic / CMYK / 4:4:0 / multi-scan -> SNCAL_ERR_UNSUPPORTED; damaged
- * streams -> SNCAL_ERR_ARG; the message names the frame.  EXIF orientation is not applied.
+ * streams -> SNCAL_ERR_ARG; the message names the frame.  A file whose EXIF orientation tag asks for a rotation / flip (cv2.imread applies it)
+ * -> SNCAL_ERR_UNSUPPORTED as well: the decoder never returns pixels cv2.imread would not.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sncal_jpeg sncal_jpeg;
 typedef struct {

@@ -145,6 +145,27 @@ Fail parse_header(const uint8_t* d, size_t len, Header& h) {
             break;
         } else if (m == 0xD9) {
             JFAIL(SNCAL_ERR_ARG, "end of image before any scan");
+        } else if (m == 0xE1 && n >= 14 && memcmp(s, "Exif\0\0", 6) == 0) {
+            // cv2.imread applies the EXIF orientation (IMREAD_COLOR without IMREAD_IGNORE_ORIENTATION); this decoder does not rotate or
+            // flip, so a frame that asks for it is refused instead of being decoded differently from the reference (make_submit.py:62)
+            const uint8_t* t = s + 6;
+            const size_t tn = n - 6;
+            const bool le = t[0] == 'I' && t[1] == 'I', be = t[0] == 'M' && t[1] == 'M';
+            auto u16 = [&](size_t o) -> unsigned { return le ? (unsigned)(t[o] | (t[o + 1] << 8)) : (unsigned)((t[o] << 8) | t[o + 1]); };
+            auto u32 = [&](size_t o) -> size_t { return le ? (size_t)u16(o) | ((size_t)u16(o + 2) << 16) : ((size_t)u16(o) << 16) | (size_t)u16(o + 2); };
+            if ((le || be) && tn >= 8 && u16(2) == 42) {
+                const size_t ifd = u32(4);
+                if (ifd + 2 <= tn) {
+                    const unsigned cnt = u16(ifd);
+                    for (unsigned k = 0; k < cnt && ifd + 2 + 12 * (size_t)(k + 1) <= tn; ++k) {
+                        const size_t e = ifd + 2 + 12 * (size_t)k;
+                        if (u16(e) == 0x0112 && u16(e + 2) == 3) {
+                            const unsigned o = u16(e + 8);
+                            if (o >= 2 && o <= 8) JFAIL(SNCAL_ERR_UNSUPPORTED, "EXIF orientation %u (cv2.imread would rotate / flip the frame; this decoder does not)", o);
+                        }
+                    }
+                }
+            }
         }
         i += 2 + L;
     }

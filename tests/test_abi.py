@@ -131,6 +131,19 @@ def test_jpeg_host_stage_matches_oracle_and_refuses_what_it_cannot_decode():
     assert status(good[:200]) == -1                                       # truncated inside the tables
     assert status(b'\x89PNG\r\n\x1a\n' + good[8:]) == -1                  # not a JPEG
     assert status(b'') == -1
+    # EXIF orientation: cv2.imread rotates / flips such frames, the decoder refuses them (orientation 1 = upright is fine)
+    import struct
+
+    def with_exif(data, orientation, little=True):
+        e = '<' if little else '>'
+        tiff = (b'II*\x00' if little else b'MM\x00*') + struct.pack(e + 'I', 8) + struct.pack(e + 'H', 1) + \
+            struct.pack(e + 'HHI', 0x0112, 3, 1) + struct.pack(e + 'HH', orientation, 0) + struct.pack(e + 'I', 0)
+        seg = b'Exif\x00\x00' + tiff
+        return data[:2] + b'\xff\xe1' + struct.pack('>H', len(seg) + 2) + seg + data[2:]
+    assert status(with_exif(good, 1)) == 0 and status(with_exif(good, 1, little=False)) == 0
+    for o in (3, 6, 8):
+        assert status(with_exif(good, o)) == -5 and b'EXIF orientation' in L.lib().sncal_last_error()
+        assert status(with_exif(good, o, little=False)) == -5
     # capacity check of the coefficient buffer
     info = L.JpegInfo()
     buf = np.zeros(64, np.int16)

@@ -206,6 +206,52 @@ def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3):
             'fp32_engine_frames_per_s': round(fps32, 1)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec under torch.distributed.run with one rank per
+    GPU (frames sharded over the GPUs of one node, one RCCL all_gather per step), so that the command the driver
+    runs verbatim measures N GPUs.  Fails loudly when fewer than N devices are visible."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    if not args.dry_dist:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus}: only {n_dev} GPU(s) visible; refusing to report a smaller job under that label')
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_dist(rank, world):
+    """--dry-dist: the multi-rank skeleton of a step on CPU (gloo) -- rendezvous, the path's one collective on rank-coded records
+    (sncal_amd.dist, the same functions the pipeline calls), barrier, max-over-ranks -- without any GPU work."""
+    import torch.distributed as dist
+    from sncal_amd.dist import gather_records, pack_records
+    if world > 1:
+        dist.init_process_group('gloo')
+    per = 4
+    kp = torch.full((per, 57, 3), float(rank), dtype=torch.float32)
+    rec = torch.full((per, 136), rank, dtype=torch.uint8)
+    t0 = time.perf_counter()
+    allrec = gather_records(pack_records(kp, rec))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    seen = sorted(set(int(v) for v in allrec[:, -1].tolist()))
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-dist (launcher / collective self-test, not a measurement)', 'value': None, 'n_gpus': world,
+                          'gathered_ranks': seen, 'records': int(allrec.shape[0]), 'record_bytes': int(allrec.shape[1]),
+                          'backend': 'gloo'}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -225,15 +271,23 @@ def main():
                     help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md 5: '
                          '2 lanes fill kernel tails and launch gaps, but per-kernel HIP-event durations then measure a shared GPU, '
                          'so the roofline object is only meaningful at 1)')
+    ap.add_argument('--dry-dist', action='store_true',
+                    help='launcher / collective self-test on CPU (gloo): the N ranks exchange rank-coded records through the '
+                         'path\'s single all_gather and rank 0 prints n_gpus and the ranks it saw; no GPU work, not a bench line')
     args = ap.parse_args()
 
+    self_launch(args)                                   # `python bench.py --gpus N`, N > 1, outside torchrun: start the N ranks
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the rank count of the launcher and --gpus must agree')
+    if args.dry_dist:
+        return dry_dist(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    if torch.cuda.device_count() < world or local >= torch.cuda.device_count():
+        raise SystemExit(f'--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU, no oversubscription)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     # SNCAL_BENCH_FORCE_DIST=1 (testing aid): take the multi-GPU code path -- RCCL init, the per-step all_gather on the

@@ -611,7 +611,7 @@ int pack_head(sncal_hrnet& net) {
     const int K1 = net.head_k, KS1 = net.head_ks1;      // stage-1 K: the first K1 concat columns (direct + folded branches)
     if (Cd > 64 || M2 > 4 || K1 > KS1 * 32) return SNCAL_OK;      // fused kernel does not apply; the reference formulation is used
     std::vector<uint16_t> w0((size_t)NQ * 2 * KS1 * 64 * 8, 0), w1((size_t)NQ * M2 * 64 * 8, 0);
-    std::vector<float> b0(HP, 0.f), b1((size_t)M2 * 16, 0.f);
+    std::vector<float> b0(HP, 0.f), b1((size_t)std::max(M2 * 16, 64), 0.f);      // head32's decode epilogue reads 64 bias slots whatever C
     for (int q = 0; q < NQ; ++q)
         for (int f = 0; f < 2; ++f)
             for (int ks = 0; ks < KS1; ++ks)

@@ -39,8 +39,8 @@ __device__ __forceinline__ void load_px16(const float* __restrict__ logits, size
 // channels each -- v[8 * k + e] = channel 16 * k + 8 * hi + e, k = 0..3 (k = quarter q of softmax_px16).  Bit-identical to
 // softmax_px16(log_mode = 1): the maximum is exact in any grouping; quarter k's sum runs 0 + e_0 + ... + e_15 in channel order, i.e.
 // through the hi = 0 lane's eight terms and on through the hi = 1 lane's; the four quarter sums combine as (s0 + s1) + (s2 + s3).
-#pragma clang fp contract(off)
 __device__ __forceinline__ void logsoftmax_px32x2(const float (&v)[32], int hi, int C, float (&r)[32]) {
+#pragma clang fp contract(off)      // scoped to this body: the summation order below is the contract, whatever the including file's FP mode
     float m = v[0];
 #pragma unroll
     for (int j = 1; j < 32; ++j) m = fmaxf(m, v[j]);

@@ -34,18 +34,37 @@ def default_calibrator(lines_file: Optional[str] = None) -> CameraCreator:
                          min_points_per_plane=6, min_points_for_refinement=6, reliable_thresh=57)
 
 
+def run_frame_size(img_dir: str, img_names: List[str], sample: int = 32):
+    """(H, W) of the run: the most frequent size among the first `sample` files whose headers the decoder accepts.  One odd file at
+    the head of os.listdir's order (a thumbnail, a progressive or damaged stream) therefore neither ends the run nor makes every
+    other frame a size mismatch.  Raises when no file of the sample can be probed."""
+    sizes = {}
+    for n in img_names[:sample]:
+        try:
+            with open(os.path.join(img_dir, n), 'rb') as f:
+                info = probe(f.read())
+        except (_lib.SncalError, OSError):
+            continue
+        key = (info['height'], info['width'])
+        sizes[key] = sizes.get(key, 0) + 1
+    if not sizes:
+        raise _lib.SncalError(f'{img_dir}: none of the first {min(sample, len(img_names))} files is a JPEG the device decoder accepts '
+                              '(baseline sequential Huffman, no EXIF rotation)')
+    return max(sizes.items(), key=lambda kv: kv[1])[0]
+
+
 def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, batch_size: int = 64,
-                decoder_threads: int = 0, img_names: Optional[List[str]] = None) -> dict:
-    """Returns {'frames', 'written', 'completeness'} (make_submit.py:72 prints the last)."""
+                decoder_threads: int = 0, img_names: Optional[List[str]] = None, max_skip_fraction: float = 0.5) -> dict:
+    """Returns {'frames', 'written', 'completeness', 'skipped'} (make_submit.py:72 prints the completeness).  Files the device
+    decoder cannot take are skipped with a warning; when more than `max_skip_fraction` of the run was skipped the function
+    raises instead of returning a near-empty result that looks like a bad model."""
     os.makedirs(save_dir, exist_ok=True)
     if img_names is None:
         img_names = [n for n in os.listdir(img_dir) if n.endswith('.jpg')]          # make_submit.py:56
     total = len(img_names)
     if total == 0:
         return {'frames': 0, 'written': 0, 'completeness': 0.0}
-    with open(os.path.join(img_dir, img_names[0]), 'rb') as f:
-        info = probe(f.read())
-    H, W = info['height'], info['width']
+    H, W = run_frame_size(img_dir, img_names)
     net = model.nn_module
     pt = model.prediction_transform
     pipe = CalibrationPipeline(net, calibrator, decode_size=(pt.H, pt.W))
@@ -107,6 +126,9 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
     drain(0)
     pipe.join()
     dec.close()
+    if len(skipped) > max_skip_fraction * total:
+        raise _lib.SncalError(f'{len(skipped)} of {total} frames were skipped (first: {skipped[0]}): more than the allowed fraction '
+                              f'{max_skip_fraction:g}; decode these frames elsewhere and feed uint8 tensors to the pipeline')
     return {'frames': total, 'written': written, 'completeness': written / total, 'skipped': skipped}
 
 

@@ -54,3 +54,31 @@ def test_gather_world2_even():
 
 def test_gather_world2_ragged():
     assert _run(37) == {0: True, 1: True}
+
+
+def _bench_cmd(*flags):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *flags], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun must start 2 ranks itself (the driver runs exactly that command line);
+    --dry-dist takes the same launcher and the path's single collective on gloo, without GPU work."""
+    import json
+    p = _bench_cmd('--gpus', '2', '--dry-dist')
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['gathered_ranks'] == [0, 1] and out['records'] == 8
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """No GPU in the CPU container: asking for 2 must fail loudly instead of reporting a 1-GPU run as n_gpus 2."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    p = _bench_cmd('--gpus', '2', '--steps', '1', '--warmup', '1')
+    assert p.returncode != 0 and 'GPU(s) visible' in (p.stderr + p.stdout)

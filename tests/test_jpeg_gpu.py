@@ -144,3 +144,39 @@ def test_directory_harness_skips_files_the_decoder_cannot_take(sncal, cuda, gold
                                        img_names=names, decoder_threads=2)
     assert res['frames'] == 4 and sorted(res['skipped']) == ['00001.jpg', '00002.jpg']
     assert res['written'] <= 2 and all(f in ('camera_00000.json', 'camera_00003.json') for f in os.listdir(save_dir))
+
+
+def test_directory_harness_survives_an_odd_first_file_and_a_stream_damaged_behind_its_headers(sncal, cuda, gold_dir, tmp_path):
+    """The run's frame size is the modal size of the probeable head of the listing, not the first file's; a stream whose entropy
+    data is corrupt passes the probe, fails inside the batch decode, and the per-frame re-decode drops only that frame.  (A stream
+    that merely ENDS early is decoded like libjpeg does it -- zero coefficients for the missing MCUs -- and is not an error.)
+    A run that lost more than max_skip_fraction of its frames raises."""
+    g, _ = _cases(gold_dir)
+    full = g['jpg.full'].tobytes()
+    small = g['jpg.48x64_420_q95_r0'].tobytes()
+    sos = full.find(b'\xff\xda')
+    assert sos > 0
+    start = sos + 2 + ((full[sos + 2] << 8) | full[sos + 3])             # first byte of the entropy-coded segment
+    cut = full[:start + 500] + b'\xff\x00' * 64 + full[start + 628:]     # 1024 one-bits: no Huffman code of the tables is that long
+    img_dir, save_dir = tmp_path / 'imgs', tmp_path / 'out'
+    img_dir.mkdir()
+    names = ['00000.jpg', '00001.jpg', '00002.jpg', '00003.jpg', '00004.jpg']
+    for n, blob in zip(names, (small, full, cut, full, full)):            # thumbnail FIRST; the cut stream shares a batch with a good one
+        (img_dir / n).write_bytes(blob)
+    cfg = hr.load_config('hrnet_w18')
+    ck = {'model_name': 'HRNetMetaModel',
+          'params': {'nn_module': {'hrnet_config': cfg, 'num_refinement_stages': 0, 'num_heatmaps': 58},
+                     'prediction_transform': {'size': [540, 960]}, 'device': 'cuda:0'},
+          'nn_state_dict': hr.seeded_state_dict(cfg, 3, 4.0)}
+    path = str(tmp_path / 'model.pth')
+    torch.save(ck, path)
+    model = sncal.load_model(path, loss=None, optimizer=None, device='cuda:0', dtype='fp32')
+    assert sncal.submit.run_frame_size(str(img_dir), names) == (540, 960)
+    with pytest.warns(UserWarning, match='skipped'):
+        res = sncal.submit.make_submit(str(img_dir), model, sncal.submit.default_calibrator(), str(save_dir), batch_size=2,
+                                       img_names=names, decoder_threads=2)
+    assert res['frames'] == 5 and sorted(res['skipped']) == ['00000.jpg', '00002.jpg']
+    assert all(f in ('camera_00001.json', 'camera_00003.json', 'camera_00004.json') for f in os.listdir(save_dir))
+    with pytest.warns(UserWarning, match='skipped'), pytest.raises(sncal._lib.SncalError, match='skipped'):
+        sncal.submit.make_submit(str(img_dir), model, sncal.submit.default_calibrator(), str(tmp_path / 'out2'), batch_size=2,
+                                 img_names=['00000.jpg', '00002.jpg', '00001.jpg'], decoder_threads=2)

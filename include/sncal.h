@@ -167,6 +167,43 @@ typedef struct {
 int sncal_hrnet_set_profiling(sncal_hrnet* net, int enable);
 int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out, int cap, int* count);
 
+/* Plan introspection + taps (test instrumentation, no reference counterpart): the per-kernel parity tests
+ * (tests/test_kernels_gpu.py) check EVERY launch of a forward -- each convolution of src/models/hrnet/hrnet.py:42-58, 79-99,
+ * 183-246, 357-391, the fuse sums of :229-244, the head of :316-329, 489-510 -- against torch fp32 on the operands that launch
+ * really read.  The plan is the flat op list the executor walks; tensors are NHWC slots of the caller's workspace.  A tap
+ * copies one tensor of the FIRST sub-batch into a caller buffer (device-to-device, on the forward's stream) when the
+ * executor passes the given op -- after the launch that ran it, also when that launch was a grouped / fused one issued at
+ * an earlier op -- while the tensor is still alive.  Taps never change what is launched. */
+typedef struct {
+    int type;                  /* 0 input layout, 1 conv, 2 upsample_add, 3 softmax, 4 decode, 5 fused head                    */
+    int active;                /* part of the plan at the current layout (head variants live side by side)                   */
+    int conv;                  /* conv unit (index as in sncal_hrnet_conv_info; >= num_convs: head-internal slice of last_layer.0) */
+    char name[96];             /* its name, "" for non-conv ops                                                                */
+    int cin, cout, ksize, stride, col_off;   /* col_off: first column of last_layer.0 of a head-internal slice               */
+    int in, res, out, base;    /* tensor ids (-1 = none)                                                                       */
+    int src[3], nsrc;          /* upsample_add sources                                                                         */
+    int head_direct, head_src[5], head_nsrc, head_fold[2], head_nfold;
+    int relu, out_coff, out_f32, fp8;        /* fp8: this conv runs in e4m3 at the current layout                            */
+    char kernel[96];           /* label of the launch that executed it in the last mode-1 profiled forward ("" = unknown or
+                                  executed by the launch of an earlier op: grouped members, second conv of a fused block)      */
+} sncal_plan_op;
+typedef struct {
+    int C, H, W;               /* NHWC, per frame                                                                              */
+    int dtype;                 /* 0 fp32, 1 bf16, 2 e4m3                                                                       */
+    int twin;                  /* id of the tensor's e4m3 twin or -1                                                           */
+    int alive;                 /* allocated at the current layout                                                              */
+    float scale;               /* e4m3 twins: value = code * scale                                                             */
+    size_t bytes;              /* of the first sub-batch (sub_batch frames)                                                    */
+    int sub_batch;
+} sncal_plan_tensor;
+int sncal_hrnet_plan_num_ops(const sncal_hrnet* net);
+int sncal_hrnet_plan_num_tensors(const sncal_hrnet* net);
+/* Valid after sncal_hrnet_workspace / a forward at the shape of interest (the layout decides sizes, twins and head variant). */
+int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_op* out);
+int sncal_hrnet_plan_tensor(const sncal_hrnet* net, int id, sncal_plan_tensor* out);
+/* Register a tap (op_idx >= 0) or clear all taps (op_idx < 0).  d_dst must hold sncal_plan_tensor.bytes. */
+int sncal_hrnet_plan_tap(sncal_hrnet* net, int op_idx, int tensor_id, void* d_dst);
+
 /* ------------------------------------------------------------------------------------------------
  * S0-S11  camera solve (batched, one wavefront per frame)
  * ---------------------------------------------------------------------------------------------- */

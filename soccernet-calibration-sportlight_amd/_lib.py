@@ -30,6 +30,23 @@ class KernelStat(ctypes.Structure):
                 ('ms', ctypes.c_double), ('launches', ctypes.c_int)]
 
 
+class PlanOp(ctypes.Structure):
+    """sncal_plan_op."""
+    _fields_ = [('type', ctypes.c_int), ('active', ctypes.c_int), ('conv', ctypes.c_int), ('name', ctypes.c_char * 96),
+                ('cin', ctypes.c_int), ('cout', ctypes.c_int), ('ksize', ctypes.c_int), ('stride', ctypes.c_int),
+                ('col_off', ctypes.c_int), ('in_', ctypes.c_int), ('res', ctypes.c_int), ('out', ctypes.c_int),
+                ('base', ctypes.c_int), ('src', ctypes.c_int * 3), ('nsrc', ctypes.c_int), ('head_direct', ctypes.c_int),
+                ('head_src', ctypes.c_int * 5), ('head_nsrc', ctypes.c_int), ('head_fold', ctypes.c_int * 2),
+                ('head_nfold', ctypes.c_int), ('relu', ctypes.c_int), ('out_coff', ctypes.c_int), ('out_f32', ctypes.c_int),
+                ('fp8', ctypes.c_int), ('kernel', ctypes.c_char * 96)]
+
+
+class PlanTensor(ctypes.Structure):
+    """sncal_plan_tensor."""
+    _fields_ = [('C', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('dtype', ctypes.c_int), ('twin', ctypes.c_int),
+                ('alive', ctypes.c_int), ('scale', ctypes.c_float), ('bytes', ctypes.c_size_t), ('sub_batch', ctypes.c_int)]
+
+
 class Camera(ctypes.Structure):
     """sncal_camera."""
     _fields_ = [('position', ctypes.c_double * 3), ('rotation', ctypes.c_double * 9),
@@ -85,6 +102,11 @@ SIGNATURES = {
     'sncal_hrnet_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
     'sncal_hrnet_calibrate_fp8': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     'sncal_hrnet_set_fp8_layers': (ctypes.c_int, [vp, ctypes.c_char_p]),
+    'sncal_hrnet_plan_num_ops': (ctypes.c_int, [vp]),
+    'sncal_hrnet_plan_num_tensors': (ctypes.c_int, [vp]),
+    'sncal_hrnet_plan_op': (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(PlanOp)]),
+    'sncal_hrnet_plan_tensor': (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(PlanTensor)]),
+    'sncal_hrnet_plan_tap': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
     'sncal_hrnet_get_profile': (ctypes.c_int, [vp, ctypes.POINTER(KernelStat), ctypes.c_int, c_int_p]),
     'sncal_pnp_refine_lm': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                            ctypes.c_double, vp]),

@@ -143,6 +143,9 @@ struct sncal_hrnet {
     size_t events_used = 0;
     std::string last_kernel;
     double last_flops = 0, last_bytes = 0;
+    // test instrumentation (sncal_hrnet_plan_tap): copies of plan tensors taken while the executor passes an op
+    struct Tap { int op, tensor; void* dst; };
+    std::vector<Tap> taps;
 };
 
 namespace {
@@ -686,6 +689,8 @@ inline bool op_active(const sncal_hrnet& net, const Op& op) {
     return op.group == GRP_ALL || (op.group == GRP_FUSED) == net.use_fused;
 }
 
+bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb);
+
 int layout(sncal_hrnet& net, int sb, int H, int W) {
     if (net.lay_sb == sb && net.lay_h == H && net.lay_w == W) return SNCAL_OK;
     for (auto& kv : net.tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
@@ -697,11 +702,38 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         const bool dims_ok = net.desc.upscale == 1 || (sh == bh * net.desc.upscale && sw == bw * net.desc.upscale);
         net.use_fused = net.fused_enabled && net.dtype == SNCAL_BF16 && dims_ok && net.d_hw0 != nullptr;
     }
-    for (ConvLayer& L : net.layers) {       // C5: which layers run in fp8 (selection set by sncal_hrnet_set_fp8_layers)
+    for (const Op& op : net.ops) {
+        if (!op_active(net, op)) continue;
+        switch (op.type) {
+            case OP_INPUT: T[op.out].H = H; T[op.out].W = W; break;
+            case OP_CONV: {
+                const ConvLayer& L = net.layers[op.conv];
+                const int pad = L.k / 2;
+                T[op.out].H = (T[op.in].H + 2 * pad - L.k) / L.stride + 1;
+                T[op.out].W = (T[op.in].W + 2 * pad - L.k) / L.stride + 1;
+                break;
+            }
+            case OP_UPADD:
+                if (op.base >= 0) { T[op.out].H = T[op.base].H; T[op.out].W = T[op.base].W; }
+                else { T[op.out].H = T[op.dims_from].H * op.dims_mul; T[op.out].W = T[op.dims_from].W * op.dims_mul; }
+                break;
+            case OP_SOFTMAX: T[op.out].H = T[op.in].H; T[op.out].W = T[op.in].W; break;
+            case OP_HEAD: T[op.out].H = T[op.head_direct].H; T[op.out].W = T[op.head_direct].W; break;
+            case OP_DECODE: break;
+        }
+    }
+    // C5: which layers run in fp8 = selected by sncal_hrnet_set_fp8_layers AND served by the two-team kernel at this size (the only
+    // kernel that reads an e4m3 twin): twins, producers' outputs and the dispatch below all key on this ONE predicate, so a selected
+    // layer that falls back to the generic kernel (SNCAL_CONV_TT=0, an odd channel offset, a size limit) simply stays bf16
+    for (ConvLayer& L : net.layers) L.fp8_on = false;
+    for (const Op& op : net.ops) {
+        if (op.type != OP_CONV || !op_active(net, op)) continue;
+        ConvLayer& L = net.layers[op.conv];
         bool w_ok = net.fp8_widths.empty();
         for (int w : net.fp8_widths) w_ok = w_ok || w == L.cout;
         const bool s_ok = net.fp8_stages == 0 || ((net.fp8_stages >> L.stage) & 1u);
-        L.fp8_on = net.fp8 && net.fp8_calibrated && !net.calibrating && L.d_w8 != nullptr && w_ok && s_ok && L.stage >= 2;
+        L.fp8_on = net.fp8 && net.fp8_calibrated && !net.calibrating && L.d_w8 != nullptr && w_ok && s_ok && L.stage >= 2 &&
+                   T[op.in].twin >= 0 && tt_eligible(net, op, sb);
     }
     for (Tensor& t : T) { t.first = -1; t.last = -1; }
     for (size_t i = 0; i < net.ops.size(); ++i) {       // lifetimes over the active ops
@@ -751,26 +783,6 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
                 Tensor& w = T[T[t].twin];
                 if (twin_used[t]) { w.first = T[t].first; w.last = T[t].last; } else { w.first = w.last = -1; }
             }
-    }
-    for (const Op& op : net.ops) {
-        if (!op_active(net, op)) continue;
-        switch (op.type) {
-            case OP_INPUT: T[op.out].H = H; T[op.out].W = W; break;
-            case OP_CONV: {
-                const ConvLayer& L = net.layers[op.conv];
-                const int pad = L.k / 2;
-                T[op.out].H = (T[op.in].H + 2 * pad - L.k) / L.stride + 1;
-                T[op.out].W = (T[op.in].W + 2 * pad - L.k) / L.stride + 1;
-                break;
-            }
-            case OP_UPADD:
-                if (op.base >= 0) { T[op.out].H = T[op.base].H; T[op.out].W = T[op.base].W; }
-                else { T[op.out].H = T[op.dims_from].H * op.dims_mul; T[op.out].W = T[op.dims_from].W * op.dims_mul; }
-                break;
-            case OP_SOFTMAX: T[op.out].H = T[op.in].H; T[op.out].W = T[op.in].W; break;
-            case OP_HEAD: T[op.out].H = T[op.head_direct].H; T[op.out].W = T[op.head_direct].W; break;
-            case OP_DECODE: break;
-        }
     }
     for (Tensor& t : T) if (t.twin >= 0) { T[t.twin].H = t.H; T[t.twin].W = t.W; }
     // first-fit allocator over op order
@@ -1348,10 +1360,10 @@ extern "C" int sncal_hrnet_calibrate_fp8(sncal_hrnet* net, const float* d_x, int
     const size_t nt = net->tensors.size();
     if (!net->d_amax) SNCAL_CHECK_HIP(hipMalloc((void**)&net->d_amax, nt * 4));
     SNCAL_CHECK_HIP(hipMemsetAsync(net->d_amax, 0, nt * 4, stream));
-    net->calibrating = true; net->lay_sb = -1;
     // keypoints into the (unused) head of the workspace would alias activations: decode into a scratch buffer of our own
     float* d_kp = nullptr;
     SNCAL_CHECK_HIP(hipMalloc((void**)&d_kp, (size_t)B * (net->desc.num_classes - 1) * 3 * 4));
+    net->calibrating = true; net->lay_sb = -1;          // set only around the forward: every exit path below sees it cleared
     const int rc = forward_impl(net, d_x, nullptr, B, H, W, nullptr, d_kp, H, W, d_ws, ws_bytes, stream_);
     net->calibrating = false; net->lay_sb = -1;
     if (rc) { (void)hipFree(d_kp); return rc; }
@@ -1412,6 +1424,53 @@ extern "C" int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out,
     return SNCAL_OK;
 }
 
+extern "C" int sncal_hrnet_plan_num_ops(const sncal_hrnet* net) { return net ? (int)net->ops.size() : 0; }
+extern "C" int sncal_hrnet_plan_num_tensors(const sncal_hrnet* net) { return net ? (int)net->tensors.size() : 0; }
+
+extern "C" int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_op* out) {
+    SNCAL_CHECK_ARG(net && out && idx >= 0 && idx < (int)net->ops.size(), "sncal_hrnet_plan_op: index %d", idx);
+    const Op& op = net->ops[idx];
+    memset(out, 0, sizeof(*out));
+    out->type = (int)op.type; out->active = op_active(*net, op) ? 1 : 0; out->conv = op.conv;
+    out->in = op.in; out->res = op.res; out->out = op.out; out->base = op.base; out->nsrc = op.nsrc;
+    for (int i = 0; i < 3; ++i) out->src[i] = op.srcs[i];
+    out->head_direct = op.head_direct; out->head_nsrc = op.head_nsrc; out->head_nfold = op.head_nfold;
+    for (int i = 0; i < 5; ++i) out->head_src[i] = i < HEAD_MAX_SRC ? op.head_src[i] : -1;
+    for (int i = 0; i < 2; ++i) out->head_fold[i] = i < HEAD_MAX_FOLD ? op.head_fold[i] : -1;
+    out->relu = op.relu ? 1 : 0; out->out_coff = op.out_coff; out->out_f32 = op.out_f32 ? 1 : 0;
+    if (op.conv >= 0) {
+        const ConvLayer& L = net->layers[op.conv];
+        snprintf(out->name, sizeof(out->name), "%s", L.name.c_str());
+        out->cin = L.cin; out->cout = L.cout; out->ksize = L.k; out->stride = L.stride; out->col_off = L.col_off;
+        out->fp8 = L.fp8_on ? 1 : 0;
+    }
+    if (idx < (int)net->op_label.size()) snprintf(out->kernel, sizeof(out->kernel), "%s", net->op_label[idx].c_str());
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_plan_tensor(const sncal_hrnet* net, int id, sncal_plan_tensor* out) {
+    SNCAL_CHECK_ARG(net && out && id >= 0 && id < (int)net->tensors.size(), "sncal_hrnet_plan_tensor: id %d", id);
+    SNCAL_CHECK_ARG(net->lay_sb > 0, "sncal_hrnet_plan_tensor: no layout yet (call sncal_hrnet_workspace or a forward first)");
+    const Tensor& t = net->tensors[id];
+    memset(out, 0, sizeof(*out));
+    out->C = t.C; out->H = t.H; out->W = t.W; out->dtype = t.f32 ? 0 : t.fp8 ? 2 : (net->dtype == SNCAL_BF16 ? 1 : 0);
+    out->twin = t.twin; out->alive = t.first >= 0 ? 1 : 0; out->scale = t.scale;
+    if (t.fp8)                      // the calibrated scale is kept on the bf16 tensor the twin belongs to
+        for (const Tensor& o : net->tensors) if (o.twin == id) out->scale = o.scale;
+    out->sub_batch = net->lay_sb;
+    out->bytes = (size_t)net->lay_sb * t.H * t.W * t.C * (t.f32 ? 4 : t.fp8 ? 1 : net->esize);
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_plan_tap(sncal_hrnet* net, int op_idx, int tensor_id, void* d_dst) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_plan_tap: null");
+    if (op_idx < 0) { net->taps.clear(); return SNCAL_OK; }
+    SNCAL_CHECK_ARG(op_idx < (int)net->ops.size() && tensor_id >= 0 && tensor_id < (int)net->tensors.size() && d_dst,
+                    "sncal_hrnet_plan_tap: op %d tensor %d", op_idx, tensor_id);
+    net->taps.push_back({op_idx, tensor_id, d_dst});
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
                                    int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     return forward_impl(net, d_x, nullptr, B, H, W, d_heat, d_kpts, img_h, img_w, d_ws, ws_bytes, stream_);
@@ -1449,8 +1508,20 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
         for (size_t oi = 0; oi < net->ops.size(); ++oi) {
             const Op& op = net->ops[oi];
             if (!op_active(*net, op)) continue;
-            if (skip_next) { skip_next = false; continue; }      // second conv of a fused BasicBlock
-            if (skip_group > 0) { --skip_group; continue; }
+            auto run_taps = [&]() -> int {                       // test instrumentation: first sub-batch only, stream-ordered copies
+                if (net->taps.empty() || b0 != 0) return SNCAL_OK;
+                for (const sncal_hrnet::Tap& tp : net->taps) {
+                    if (tp.op != (int)oi) continue;
+                    const Tensor& tt = net->tensors[tp.tensor];
+                    if (tt.first < 0) { set_error("sncal_hrnet_plan_tap: tensor %d is not allocated at this layout", tp.tensor); return SNCAL_ERR_STATE; }
+                    const void* src = tt.external_heat ? (const void*)heat : (const void*)(ws + tt.offset);
+                    const size_t nb = (size_t)sb * tt.H * tt.W * tt.C * (tt.f32 ? 4 : tt.fp8 ? 1 : net->esize);
+                    SNCAL_CHECK_HIP(hipMemcpyAsync(tp.dst, src, nb, hipMemcpyDeviceToDevice, stream));
+                }
+                return SNCAL_OK;
+            };
+            if (skip_next) { skip_next = false; rc = run_taps(); if (rc) return rc; continue; }      // second conv of a fused BasicBlock
+            if (skip_group > 0) { --skip_group; rc = run_taps(); if (rc) return rc; continue; }
             net->last_kernel.clear(); net->last_flops = 0; net->last_bytes = 0;
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (net->op_label.size() != net->ops.size()) net->op_label.assign(net->ops.size(), std::string());
@@ -1604,6 +1675,8 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     if (d_kpts && !decoded) rc = sncal_heatmap_decode(heat, sb, C, th.H, th.W, img_h, img_w, d_kpts + (size_t)b0 * (C - 1) * 3, stream_);
                     break;
             }
+            if (rc) return rc;
+            rc = run_taps();
             if (rc) return rc;
             if (net->profiling) {
                 sncal::LaunchEvents& le = sncal::launch_events();

@@ -240,6 +240,44 @@ class HRNetHeatmap:
         return [dict(kernel=buf[i].kernel.decode(), flops=buf[i].flops, bytes=buf[i].bytes, ms=buf[i].ms,
                      launches=buf[i].launches) for i in range(min(n.value, 256))]
 
+    # ---- plan introspection + taps (test instrumentation: tests/test_kernels_gpu.py) -----------------------------
+    OP_TYPES = ('input', 'conv', 'upsample_add', 'softmax', 'decode', 'head')
+
+    def plan_ops(self):
+        """The executor's op list at the current layout (valid after a forward / workspace query): list of dicts."""
+        out = []
+        po = _lib.PlanOp()
+        for i in range(self._L.sncal_hrnet_plan_num_ops(self._h)):
+            _lib.check(self._L.sncal_hrnet_plan_op(self._h, i, ctypes.byref(po)), 'plan_op')
+            out.append(dict(idx=i, type=self.OP_TYPES[po.type], active=bool(po.active), conv=po.conv, name=po.name.decode(),
+                            cin=po.cin, cout=po.cout, ksize=po.ksize, stride=po.stride, col_off=po.col_off,
+                            **{'in': po.in_}, res=po.res, out=po.out, base=po.base, src=list(po.src)[:po.nsrc],
+                            head_direct=po.head_direct, head_src=list(po.head_src)[:po.head_nsrc],
+                            head_fold=list(po.head_fold)[:po.head_nfold], relu=bool(po.relu), out_coff=po.out_coff,
+                            out_f32=bool(po.out_f32), fp8=bool(po.fp8), kernel=po.kernel.decode()))
+        return out
+
+    def plan_tensor(self, tid):
+        pt = _lib.PlanTensor()
+        _lib.check(self._L.sncal_hrnet_plan_tensor(self._h, tid, ctypes.byref(pt)), 'plan_tensor')
+        return dict(id=tid, C=pt.C, H=pt.H, W=pt.W, dtype=('fp32', 'bf16', 'e4m3')[pt.dtype], twin=pt.twin, alive=bool(pt.alive),
+                    scale=pt.scale, bytes=pt.bytes, sub_batch=pt.sub_batch)
+
+    def clear_taps(self):
+        _lib.check(self._L.sncal_hrnet_plan_tap(self._h, -1, 0, None), 'plan_tap')
+        self._taps = []
+
+    def tap(self, op_idx, tid):
+        """Ask the next forward(s) to copy tensor `tid` (first sub-batch, NHWC) when the executor passes op `op_idx`.
+        Returns the destination tensor (sub_batch, H, W, C) in the tensor's storage type."""
+        info = self.plan_tensor(tid)
+        tdt = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'e4m3': torch.uint8}[info['dtype']]
+        dst = torch.empty((info['sub_batch'], info['H'], info['W'], info['C']), dtype=tdt, device=self.device)
+        assert dst.numel() * dst.element_size() == info['bytes'], info
+        _lib.check(self._L.sncal_hrnet_plan_tap(self._h, op_idx, tid, dst.data_ptr()), 'plan_tap')
+        self._taps = getattr(self, '_taps', []) + [dst]          # keep the buffers alive while the taps are registered
+        return dst
+
     def __call__(self, x):
         """Reference nn.Module contract: list of stage outputs, [-1] is the head output."""
         return [self.forward(x, want_heat=True)[0]]

@@ -90,10 +90,11 @@ def _desc(cfg):
 
 
 class HRNetHeatmap:
-    """Inference-only HRNet on the HIP engine.  ``dtype``: 'bf16' (fast path) or 'fp32' (parity path)."""
+    """Inference-only HRNet on the HIP engine.  ``dtype``: 'fp32' (default: the reference's arithmetic, exact-fp32 MFMA engine),
+    'bf16' (throughput mode) or 'fp8' (bf16 engine with e4m3 wide convolutions, BASELINE config C5)."""
 
     def __init__(self, hrnet_config, num_refinement_stages: int = 0, num_heatmaps: int = None,
-                 dtype: str = 'bf16', device='cuda:0', head=None, upscale=None):
+                 dtype: str = 'fp32', device='cuda:0', head=None, upscale=None):
         if num_refinement_stages != 0:
             raise _lib.SncalError('refinement stages are never instantiated by the reference configs; unsupported')
         self.cfg = load_config(hrnet_config, head=head, upscale=upscale)

@@ -140,7 +140,7 @@ def main(argv=None):
     ap.add_argument('--lines-file', default=None, help='lines pickle of export_line_result.py (optional)')
     ap.add_argument('--batch-size', type=int, default=64)
     ap.add_argument('--device', default='cuda:0')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='fp32: the reference\'s arithmetic (default); bf16: throughput mode, keypoints may move by one cell on near-ties')
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise _lib.SncalError('no GPU visible: this package has no CPU path')

@@ -88,9 +88,14 @@ def stamp_codes() -> np.ndarray:
     return np.stack(codes).reshape(57, 3, 2, 2).astype(np.float32)
 
 
-def peaked_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.25) -> dict:
-    """Copy of the random-init HRNet state dict `sd` (keypoint net, 58 classes, stem 64) with the signal path installed."""
+def peaked_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.25, deep: bool = False, **deep_kw) -> dict:
+    """Copy of the random-init HRNet state dict `sd` (keypoint net, 58 classes, stem 64) with the signal path installed.
+    deep=False: stem channel k -> hidden k -> logit k (the head reads the stem features directly; the backbone only adds noise).
+    deep=True:  the keypoint code travels THROUGH the backbone and reaches the head through the upsampled branch channels only
+                (deep_state_dict below); the stem columns of last_layer.0 are zero for the signal rows."""
     import torch
+    if deep:
+        return deep_state_dict(sd, peak_logit=peak_logit, noise_gain=noise_gain, **deep_kw)
     out = {k: v.clone() for k, v in sd.items()}
     codes = torch.from_numpy(stamp_codes())
     w = out['model.conv1.weight']                       # (64,3,3,3), stride 2, pad 1: taps 1..2 see cell (2i..2i+1, 2j..2j+1)
@@ -111,6 +116,151 @@ def peaked_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.
     b1 = out['model.last_layer.3.bias']
     b1 *= noise_gain
     b1[57] += peak_logit / 2.0
+    return out
+
+
+# ---- deep signal path ---------------------------------------------------------------------------------------------
+# The shallow path above decides a peak's position in the stem conv and the head; 55 % of a step's GPU time (the two-team
+# convolutions, the fused 48-channel blocks, the fuse sums, every fp8 layer) only adds noise to it.  The deep path routes
+# keypoint class k through channel k of EVERY backbone tensor, on layers the reference network really has, so that the
+# position of a heatmap peak is decided by tensors those kernels wrote (hrnet.py:437-511 forward; BasicBlock :42-58;
+# fuse layers :183-246; transitions :357-391):
+#   conv1 (stem, stride 2)         matched filter of code k, as above                     -> stem k = relu(2 env - 1) at 270x480
+#   conv2 (stride 2)               row k: tent kernel on stem channel k, gain `amp`       -> channel k of the 135x240 map
+#   layer1.0.downsample            row k: identity on channel k (the Bottleneck chain then carries it on its residual path)
+#   transition1.0 / .1             row k: centre tap (k < 48) / stride-2 tent (k < 57)     -> branch 0 (48 ch: classes 0..47) and 1
+#   transition2.2, transition3.3   row k: stride-2 tent from the branch above              -> branches 2 and 3 (all 57 classes)
+#   every BasicBlock               conv1[k,k] += a1, conv2[k,k] += a2 (BN-compensated centre taps) ON TOP of the random rows:
+#                                  out_k = relu(x_k + a2 relu(a1 x_k + noise) + noise): the code passes through the residual
+#                                  add AND through both multiplies; (1 + a1 a2)^32 = 4.8 over the 32 blocks of a branch, so
+#                                  79 % of what arrives has been through at least one conv multiply
+#   every fuse layer               row k: 1x1 [k,k] = fuse_gain (up) / stride-2 tent chain with gain fuse_gain (down): the code
+#                                  of class k is exchanged between the resolutions exactly as HRNet exchanges features
+#   last_layer.0                   hidden k reads channel k of up(branch 0..3) (concat columns 64+, NOT the stem's), minus a cut
+#   last_layer.3                   logit k = gain_k x hidden k; everything else random x noise_gain, as above
+# The random rows of every BasicBlock convolution keep feeding pixel- and class-dependent noise into channel k (that is what
+# makes near-ties), rows k of the transition / fuse / downsample convolutions are replaced (an exact carry).  A peak now sits
+# on the fine-grid cell next to a coarse-grid node (4 px grid for classes 0..47, which ride branch 0; 8 px for 48..56), no
+# longer exactly on the stamped cell.  gain_k comes from a noise-free single-channel simulation of the same path.
+
+_TENT = np.array([[0.25, 0.5, 0.25], [0.5, 1.0, 0.5], [0.25, 0.5, 0.25]], dtype=np.float32)       # sum 4: unit DC gain at stride 2 is _TENT / 4
+
+
+def _signal_peak(has_b0: bool, amp: float, a12: float, fg: float, sigma_cells: float = 2.0) -> float:
+    """Noise-free response of ONE signal channel at the head (sum over the four upsampled branches) to a stamp of unit stem
+    amplitude, on a 128x128 crop of the stem grid; the stamp sits where the coarse grids line up (cell 64, 64)."""
+    import torch
+    import torch.nn.functional as F
+    n = 128
+    yy, xx = np.mgrid[0:n, 0:n]
+    env = np.exp(-((yy - 64) ** 2 + (xx - 64) ** 2) / (2.0 * sigma_cells ** 2))
+    stem = torch.from_numpy(np.maximum(2.0 * env - 1.0, 0.0).astype(np.float32))[None, None]
+    tent = torch.from_numpy(_TENT / 4.0)[None, None]
+
+    def down(t):
+        return F.conv2d(t, tent, stride=2, padding=1)
+
+    def up(t, size):
+        return F.interpolate(t, size=size, mode='bilinear', align_corners=True)
+    s = amp * down(stem)
+    b = [s if has_b0 else torch.zeros_like(s), down(s)]
+    blocks = (1.0 + a12) ** 4
+    for nb, nm in ((2, 1), (3, 4), (4, 3)):
+        if len(b) < nb:
+            b.append(down(b[-1]))
+        for _ in range(nm):
+            b = [t * blocks for t in b]
+            out = []
+            for i in range(nb):
+                y = b[i].clone()
+                for j in range(nb):
+                    if j > i:
+                        y = y + fg * up(b[j], b[i].shape[-2:])
+                    elif j < i:
+                        t = b[j]
+                        for q in range(i - j):
+                            t = down(t) * (fg if q == i - j - 1 else 1.0)
+                        y = y + t
+                out.append(y if (i > 0 or has_b0) else torch.zeros_like(y))
+            b = out
+    h = sum(up(t, (n, n)) for t in b)
+    return float(h.max())
+
+
+def deep_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.25, amp: float = 48.0, a1: float = 0.5,
+                    a2: float = -0.04, fuse_gain: float = 0.1, cut: float = 0.25, boost: float = 3.0, row_gain: float = 0.1) -> dict:
+    """See the block comment above.  `sd`: random-init HRNet-W48-shaped keypoint state dict (58 classes, stem 64, branch widths
+    48 / 96 / 192 / 384 or any widths with >= 57 channels from branch 1 on)."""
+    import torch
+    out = peaked_state_dict(sd, peak_logit=peak_logit, noise_gain=noise_gain)          # stem filters + last_layer.3 noise scaling
+    eps = 1e-5
+    tent = torch.from_numpy(_TENT)
+
+    def ident_bn(bn, n):
+        for key, val in (('weight', 1.0), ('bias', 0.0), ('running_mean', 0.0), ('running_var', 1.0 - eps)):
+            out[f'{bn}.{key}'][:n] = val
+
+    def carry(conv, bn, n, kernel, gain=1.0):
+        """rows < n of `conv` := `kernel` (3x3 tensor, or None for a 1x1 / centre tap) x gain on the diagonal; BN identity there."""
+        w = out[conv + '.weight']
+        n = min(n, w.shape[0])
+        w[:n] = 0.0
+        m = min(n, w.shape[1])
+        idx = torch.arange(m)
+        if kernel is None:
+            w[idx, idx, w.shape[2] // 2, w.shape[3] // 2] = gain
+        else:
+            w[idx, idx] = kernel * gain
+        ident_bn(bn, n)
+
+    carry('model.conv2', 'model.bn2', 57, tent / 4.0, amp)
+    carry('model.layer1.0.downsample.0', 'model.layer1.0.downsample.1', 57, None)
+    widths = {}
+    for key, v in out.items():           # branch widths from the block convolutions themselves
+        if key.startswith('model.stage4.0.branches.') and key.endswith('.0.conv1.weight'):
+            widths[int(key.split('.')[4])] = v.shape[0]
+    carry('model.transition1.0.0', 'model.transition1.0.1', min(57, widths[0]), None)
+    carry('model.transition1.1.0.0', 'model.transition1.1.0.1', 57, tent / 4.0)
+    if widths[0] < 57:                  # classes that find no channel in branch 0 enter branch 1 `boost` times stronger
+        out['model.transition1.1.0.0.weight'][widths[0]:57] *= boost
+    carry('model.transition2.2.0.0', 'model.transition2.2.0.1', 57, tent / 4.0)
+    carry('model.transition3.3.0.0', 'model.transition3.3.0.1', 57, tent / 4.0)
+    for key in [k for k in out if '.branches.' in k and k.endswith(('.conv1.weight', '.conv2.weight'))]:
+        conv = key[:-len('.weight')]
+        bn = conv.replace('.conv1', '.bn1').replace('.conv2', '.bn2')
+        w = out[key]
+        n = min(57, w.shape[0])
+        idx = torch.arange(n)
+        scale = out[bn + '.weight'][:n] / torch.sqrt(out[bn + '.running_var'][:n] + eps)          # the BN that follows multiplies by this
+        if conv.endswith('conv2'):
+            w[:n] *= row_gain                       # how strongly the random network (noise + the other classes' codes) writes into channel k
+        w[idx, idx, 1, 1] += (a1 if conv.endswith('conv1') else a2) / scale
+    for key in [k for k in out if '.fuse_layers.' in k and k.endswith('.0.weight')]:
+        conv = key[:-len('.weight')]
+        bn = conv[:-1] + '1'
+        parts = conv.split('.')                   # model.stageS.M.fuse_layers.I.J.0   or   ...I.J.Q.0
+        i, j = int(parts[4]), int(parts[5])
+        if j > i:
+            carry(conv, bn, 57, None, fuse_gain)
+        else:
+            q = int(parts[6])
+            carry(conv, bn, 57, tent / 4.0, fuse_gain if q == i - j - 1 else 1.0)
+    # head: hidden k <- channel k of the upsampled branches (concat order: stem 64 | b0 | b1 | b2 | b3), cut, logit gain
+    w0 = out['model.last_layer.0.weight']
+    w0[:57] = 0.0
+    off = 64
+    for b in sorted(widths):
+        n = min(57, widths[b])
+        idx = torch.arange(n)
+        w0[idx, off + idx, 0, 0] = 1.0
+        off += widths[b]
+    ident_bn('model.last_layer.1', 57)
+    w1 = out['model.last_layer.3.weight']
+    peaks = {True: _signal_peak(True, amp, a1 * a2, fuse_gain), False: boost * _signal_peak(False, amp, a1 * a2, fuse_gain)}
+    for k in range(57):
+        pk = peaks[k < widths[0]]
+        out['model.last_layer.0.bias'][k] = -cut * pk
+        w1[k, k, 0, 0] = peak_logit / ((1.0 - cut) * pk)
     return out
 
 

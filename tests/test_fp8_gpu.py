@@ -63,13 +63,13 @@ def test_fp8_plumbing_small(sncal, cuda):
 
 
 def test_c5_w48_fp8_1080p_tolerance_sweep(sncal, cuda):
-    """C5 at its own size: W48, 1920x1080 (heatmaps 540x960, 1-px decode grid), peaked workload, B = 2.  For every layer
-    selection: keypoint-index agreement with the fp32 engine (over the keypoints the solver can use, and over all rows),
-    and the relative difference of the solved cameras' reprojection error.  The table goes to gpurun_out/ (committed under
-    profiles/); asserted: 'none' equals the bf16 engine, and the all-fp8 network still finds the stamped keypoints and
-    cameras with rmse within 5 % of the fp32 engine's (the measured numbers are far inside; see the table)."""
-    B = 2
-    sd = _weights(sncal)
+    """C5 at its own size: W48, 1920x1080 (heatmaps 540x960, 1-px decode grid), DEEP-PATH workload (the keypoint codes travel through
+    the e4m3 layers themselves, synth.deep_state_dict), B = 16.  For every layer selection: keypoint-index agreement with the fp32
+    engine (over the keypoints the solver can use, and over all rows), how far keypoints move, and the relative difference of the
+    solved cameras' reprojection error on ALL frames with two cameras.  The table goes to gpurun_out/ (committed under profiles/);
+    asserted: 'none' equals the bf16 engine, every selection keeps the cameras, and agreement does not collapse."""
+    B = 16
+    sd = _weights(sncal, deep=True)
     frames, expect = sncal.synth.stamped_frames(B, seed=4242, size=(1080, 1920))
     x = torch.from_numpy(frames).to(cuda)
     vis = expect[..., 2] > 0
@@ -79,17 +79,17 @@ def test_c5_w48_fp8_1080p_tolerance_sweep(sncal, cuda):
     kp32 = kp32.cpu().numpy()
     del n32
     torch.cuda.empty_cache()
-    assert float((kp32[..., :2] == expect[..., :2]).all(-1)[vis].mean()) >= 0.99
+    usable = kp32[..., 2] >= 0.2
+    assert float((np.abs(kp32[..., :2] - expect[..., :2]).max(-1) <= 8.0)[vis & usable].mean()) >= 0.95
     cc = sncal.CameraCreator(sncal.PITCH_POINTS, **KW)
     c32 = cc.solve_batch(kp32)
-    usable = kp32[..., 2] >= 0.2
     nb = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
     nb.load_state_dict(sd)
     _, kpb = nb.forward(x, want_heat=False, decode_size=(540, 960))
     del nb
     n8 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp8', device=cuda)
     n8.load_state_dict(sd)
-    n8.calibrate_fp8(x)
+    n8.calibrate_fp8(x[:4])
     rows = []
     for spec in SPECS:
         n8.set_fp8_layers(spec)
@@ -101,24 +101,25 @@ def test_c5_w48_fp8_1080p_tolerance_sweep(sncal, cuda):
             assert torch.equal(kp, kpb)
         kp = kp.cpu().numpy()
         same = (kp[..., :2] == kp32[..., :2]).all(-1)
+        move = np.abs(kp[..., :2] - kp32[..., :2]).max(-1)
         cams = cc.solve_batch(kp)
-        deltas = [abs(c.rmse - r.rmse) / r.rmse for c, r in zip(cams, c32) if c is not None and r is not None]
+        deltas = [abs(c.rmse - r.rmse) / r.rmse for c, r in zip(cams, c32) if c is not None and r is not None and r.rmse > 0]
         fp8_ms = prof.get('conv_tt<fp8,k3,s1,8x32x96>', {}).get('ms', 0.0)
         bf_ms = prof.get('conv_tt<bf16,k3,s1,8x32x96>', {}).get('ms', 0.0)
         rows.append({'fp8_layers': spec, 'index_agreement_usable': round(float(same[usable].mean()), 6),
                      'index_agreement_all_rows': round(float(same.mean()), 6),
+                     'moved_usable_max_px': float(move[usable].max()), 'moved_usable': int((move[usable] > 0).sum()), 'usable': int(usable.sum()),
                      'conf_delta_max_usable': round(float(np.abs(kp[..., 2] - kp32[..., 2])[usable].max()), 5),
                      'cameras': sum(c is not None for c in cams), 'cameras_fp32': sum(c is not None for c in c32),
-                     'rmse_rel_delta_max': max(deltas) if deltas else None,
+                     'rmse_rel_delta_max': max(deltas) if deltas else None, 'rmse_rel_delta_median': float(np.median(deltas)) if deltas else None,
+                     'frames_rmse_le_1e-4': int(sum(d <= 1e-4 for d in deltas)), 'frames_both': len(deltas),
                      'wide_conv_ms_fp8_kernel': round(fp8_ms, 3), 'wide_conv_ms_bf16_kernel': round(bf_ms, 3)})
         print('FP8SWEEP', json.dumps(rows[-1]))
     try:
         os.makedirs('gpurun_out', exist_ok=True)
         with open(os.path.join('gpurun_out', 'fp8_sweep_1080p.json'), 'w') as f:
-            json.dump({'workload': 'HRNet-W48 1920x1080, peaked heatmaps (synth.py), B=2, vs the exact-fp32 engine', 'rows': rows}, f, indent=1)
+            json.dump({'workload': 'HRNet-W48 1920x1080, deep-path workload (synth.deep_state_dict), B=16, vs the exact-fp32 engine; row "none" = the bf16 engine', 'rows': rows}, f, indent=1)
     except OSError:
         pass
-    full = rows[-1]
-    assert full['fp8_layers'] == 'all' and full['cameras'] == full['cameras_fp32'] == B
-    assert full['index_agreement_usable'] >= 0.95, full
-    assert full['rmse_rel_delta_max'] is not None and full['rmse_rel_delta_max'] <= 0.05, full
+    for r in rows:
+        assert r['cameras'] >= r['cameras_fp32'] - 1 and r['index_agreement_usable'] >= 0.9 and r['moved_usable_max_px'] <= 8.0, r

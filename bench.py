@@ -172,38 +172,69 @@ def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0, nb=8):
             'serial_fps': round(1.0 / (t_net + t_dec + 1.0 / fps_pool), 4)}
 
 
-def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3):
-    """The benchmarked engine vs this build's exact-fp32 engine on the SAME frames (outside the timed region)."""
+def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, flop_frame=None):
+    """The benchmarked engine vs this build's exact-fp32 engine on the SAME frames (outside the timed region).  Returns (parity,
+    fp32): `fp32` is the reference-precision leg of the line -- HRNetMetaModel.predict is fp32 (metamodel.py:127-134) -- measured
+    like the main leg: the same step (forward + fused decode + solve of the decoded keypoints), warm-up, one step profiled launch by
+    launch to find the dominant kernel, then `steps` timed steps with HIP events on that kernel's launches only."""
     net32 = sncal_amd.HRNetHeatmap(cfg_name, dtype='fp32', device=dev)
     net32.load_state_dict(sd)
     pipe = sncal_amd.CalibrationPipeline(net32, cc, decode_size=(540, 960))
     out = pipe.submit(x)
     pipe.join()
     torch.cuda.synchronize()
+    net32.set_profiling(1)
+    pipe.submit(x)
+    pipe.join()
+    torch.cuda.synchronize()
+    warm = net32.get_profile()
+    net32.set_profiling(2)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = pipe.submit(x)
     pipe.join()
     torch.cuda.synchronize()
-    fps32 = steps * x.shape[0] / (time.perf_counter() - t0)
+    dt32 = time.perf_counter() - t0
+    dom = net32.get_profile()
+    net32.set_profiling(0)
+    fps32 = steps * x.shape[0] / dt32
+    fp32 = {'value': round(fps32, 2), 'unit': 'frames/s', 'ms_per_step': round(dt32 / steps * 1e3, 2), 'steps': steps, 'frames': int(x.shape[0]),
+            'dtype': 'fp32', 'what': 'the same step on the exact-fp32 MFMA engine (v_mfma_f32_16x16x4_f32): the reference\'s own arithmetic, load_model\'s default'}
+    if len(dom) == 1 and dom[0]['ms'] > 0:
+        d = dom[0]
+        tot = sum(p['ms'] for p in warm)
+        wd = next((p for p in warm if p['kernel'] == d['kernel']), None)
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        fp32['roofline'] = {'bound': 'mfma', 'kernel': d['kernel'], 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
+                            'frac': round(ach / PEAK_TFLOPS['fp32'], 4), 'launches': d['launches'],
+                            'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2),
+                            'share_of_gpu_time': round(wd['ms'] / tot, 4) if wd and tot else None}
+        if flop_frame:
+            fp32['network_tflops_reference_formulation'] = round(fps32 * flop_frame / 1e12, 1)
+            fp32['network_frac_of_fp32_mfma_peak'] = round(fps32 * flop_frame / 1e12 / PEAK_TFLOPS['fp32'], 4)
     kp32 = out[0].cpu().numpy()
     kpf = kp_fast.cpu().numpy()
     same = (kp32[..., :2] == kpf[..., :2]).all(-1)                       # (B,57) identical (x, y) indices
     usable = kp32[..., 2] >= 0.2                                         # rows any of the solver's thresholds can take
+    move = np.abs(kp32[..., :2] - kpf[..., :2]).max(-1)
     # both keypoint sets through the same solve call (no line points), so the comparison is like for like in every workload
     r32, rf = cc.records(out[1]), cc.records(cc.solve_device(kp_fast))
     both = [i for i in range(len(r32)) if r32[i].status != 0 and rf[i].status != 0]
-    deltas = [abs(rf[i].rmse - r32[i].rmse) / r32[i].rmse for i in both if r32[i].rmse > 0]
-    return {'vs': 'exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py)',
-            'frames': int(x.shape[0]),
-            'index_agreement': round(float(same[usable].mean()) if usable.any() else 1.0, 6),
-            'usable_keypoints': int(usable.sum()),
-            'index_agreement_all_rows': round(float(same.mean()), 6),
-            'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
-            'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_benchmarked': sum(r.status != 0 for r in rf),
-            'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
-            'solve_parity': 'vs the build\'s own oracle only: OpenCV parity unpinned (cv2 not installable offline)',
-            'fp32_engine_frames_per_s': round(fps32, 1)}
+    deltas = [abs(rf[i].rmse - r32[i].rmse) / r32[i].rmse for i in both if r32[i].rmse > 0]      # ALL frames with two cameras
+    parity = {'vs': 'exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py, kernel by kernel to torch fp32 by tests/test_kernels_gpu.py)',
+              'workload': 'deep path: the keypoint codes travel through every backbone tensor (synth.deep_state_dict)',
+              'frames': int(x.shape[0]),
+              'index_agreement': round(float(same[usable].mean()) if usable.any() else 1.0, 6),
+              'usable_keypoints': int(usable.sum()),
+              'moved_usable_keypoints': int((~same[usable]).sum()), 'moved_usable_max_px': float(move[usable].max()) if usable.any() else 0.0,
+              'index_agreement_all_rows': round(float(same.mean()), 6),
+              'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
+              'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_benchmarked': sum(r.status != 0 for r in rf),
+              'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
+              'rmse_rel_delta_median': float(f'{float(np.median(deltas)):.3e}') if deltas else None,
+              'frames_rmse_rel_delta_le_1e-4': int(sum(d <= 1e-4 for d in deltas)),
+              'solve_parity': 'vs the build\'s own oracle only: OpenCV parity unpinned (cv2 not installable offline)'}
+    return parity, fp32
 
 
 def self_launch(args):
@@ -460,11 +491,34 @@ def main():
                          'flops_per_launch': round(dom['flops'] / dom['launches'], 0),
                          'share_of_gpu_time': round(warm_dom['ms'] / total_ms, 4)},
         }
+        # the next kernels of the step (last warm-up step, every launch timed): fraction of the roof that bounds each + PMC traffic ratio
+        kernels = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                pmc = json.load(f) if args.size == '540p' else {}
+        except OSError:
+            pmc = {}
+        for p in sorted(warm, key=lambda q: -q['ms'])[:6]:
+            if not p['ms'] or not p['launches']:
+                continue
+            k = p['kernel']
+            tf = p['flops'] / (p['ms'] * 1e-3) / 1e12
+            gbs = p['bytes'] / (p['ms'] * 1e-3) / 1e9
+            row = {'share_of_gpu_time': round(p['ms'] / total_ms, 4), 'launches_per_step': p['launches'], 'avg_launch_us': round(p['ms'] * 1e3 / p['launches'], 1),
+                   'tflops': round(tf, 1), 'frac_mfma': round(tf / (PEAK_TFLOPS['fp8'] if 'fp8' in k else PEAK_TFLOPS['bf16']), 4),
+                   'algorithmic_gb_s': round(gbs, 0), 'frac_hbm': round(gbs / 8000.0, 4)}
+            if k in pmc:
+                row['pmc_bytes_per_launch'] = pmc[k]
+                row['pmc_over_algorithmic'] = round(pmc[k] / (p['bytes'] / p['launches']), 3) if p['bytes'] else None
+                row['pmc_gb_s'] = round(pmc[k] / (p['ms'] * 1e-3 / p['launches']) / 1e9, 0)
+            kernels[k] = row
+        out['kernels'] = kernels
         if world == 1 and not args.no_parity:
             for n in nets[1:] + lnets:
                 n._ws = None
             npar = B if args.size == '540p' else min(B, 16)
-            out['parity'] = parity_leg(sncal_amd, cfg_name, sd, x[:npar], cc, kp_fast[:npar], rec_fast[:npar], dev)
+            out['parity'], out['fp32'] = parity_leg(sncal_amd, cfg_name, sd, x[:npar], cc, kp_fast[:npar], rec_fast[:npar], dev,
+                                                    flop_frame=FLOP_KEYPOINT_NET if args.size == '540p' else FLOP_KEYPOINT_NET_1080P)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf, nb=8 if args.size == '540p' else 2)
         print(json.dumps(out), flush=True)

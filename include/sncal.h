@@ -236,9 +236,16 @@ typedef struct {              /* CameraCreator kwargs, make_submit.py:45-50     
     int min_points, min_points_per_plane, min_points_for_refinement, reliable_thresh;
     double min_focal_length;
     int img_w, img_h;
+    int lm_schedule;          /* 0 (default) = the minimisers follow OpenCV 4.7's own schedules as far as they are known:
+                                 LMSolver for solvePnPRefineLM (lambda_0 = 1, D fixed, gain ratio, stop 1e-5), CvLevMarq for the
+                                 extrinsics refits (20 iterations / FLT_EPSILON) and calibrateCamera's joint fit (30 / DBL_EPSILON);
+                                 1 = run every minimiser to convergence (the build's round-1/2 specification).  OpenCV parity is
+                                 unpinned either way (cv2 is not installable offline)                                         */
 } sncal_voter_cfg;
 
-/* Camera.refine_camera  baseline/camera.py:105-119 (cv.solvePnPRefineLM, K fixed, 6-DoF pose LM).
+/* Camera.refine_camera  baseline/camera.py:105-119 (cv.solvePnPRefineLM, K fixed, 6-DoF pose LM; LMSolver's schedule, see
+ * sncal_voter_cfg.lm_schedule; max_iters <= 0 / eps <= 0 select the reference's criteria (20000, 1e-5); the environment variable
+ * SNCAL_SOLVE_SCHEDULE=converged switches this entry and sncal_solve_pnp to the run-to-convergence minimisers).
  *   d_K (B,4) fx,fy,cx,cy   d_pts3d (B,N,3) fp64   d_pts2d (B,N,2) fp64   d_npts (B) int32
  *   d_rt (B,12) in/out: rotation row-major (9) + position (3)   d_rmse (B) out mean-L2 px */
 int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d,

@@ -45,16 +45,22 @@ from .pitch import GOAL_LEFT, GOAL_RIGHT, GROUND, KEEP_POINTS, TOP_GATES, pitch_
 # bound the UNPINNED gap to OpenCV: `opencv_stops()` = calibrateCamera's default criteria of 30 joint iterations and
 # solvePnPRefineLM's criteria (20000, 1e-5) on step and residual (SURVEY 8c notes; the damping schedule stays the build's
 # own); `iac_failure='reference'` = go on with K = I as prediction.py:514 does.
-STOP = dict(joint_iters=60, pose_iters=100, pose_eps=1e-10, pose_res_eps=0.0, iac_failure='drop')
+STOP = dict(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
 COUNTERS = dict(iac_failures=0)
+FLT_EPSILON = 1.1920928955078125e-07
+DBL_EPSILON = 2.220446049250313e-16
 
 
 def opencv_stops():
-    STOP.update(joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5)
+    """DEFAULT since round 3: the minimisers follow OpenCV 4.7's own schedules as far as they are known (SURVEY 8c notes, restated
+    from the upstream sources from memory -- still UNPINNED): LMSolver for solvePnPRefineLM (lm_solver_pose), CvLevMarq for the
+    extrinsics refinements (cvlevmarq_pose, 20 iterations / FLT_EPSILON) and for calibrateCamera's joint fit (30 / DBL_EPSILON)."""
+    STOP.update(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5)
 
 
 def converged_stops():
-    STOP.update(joint_iters=60, pose_iters=100, pose_eps=1e-10, pose_res_eps=0.0)
+    """The build's round-1/2 specification: every minimiser runs to convergence under its own x10 / /10 damping schedule."""
+    STOP.update(schedule='converged', joint_iters=60, pose_iters=100, pose_eps=1e-10, pose_res_eps=0.0)
 
 
 P64 = pitch_points()
@@ -311,6 +317,206 @@ def refine_pose_lm(R, t, K4, X, uv, max_iters: int = 100, eps: float = 1e-10):
     return _polar(R), t
 
 
+# ------------------------------------------------------------------------------------------------
+# OpenCV's own minimiser schedules (opencv-python 4.7.0.72, restated from the upstream sources from memory: UNPINNED)
+# ------------------------------------------------------------------------------------------------
+
+def log_so3(R):
+    """cv.Rodrigues(matrix -> vector) for an orthonormal R: axis * angle."""
+    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) * 0.5))
+    th = np.arccos(c)
+    a = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) * 0.5          # sin(th) * axis
+    s = np.linalg.norm(a)
+    if s < 1e-5:
+        if c > 0:
+            return a.copy()                                   # th ~ 0: r ~ the antisymmetric part
+        # th ~ pi: axis from the symmetric part (R + I) / 2 = axis axis^T, sign from the antisymmetric part where it still speaks
+        B = (R + np.eye(3)) * 0.5
+        ax = np.sqrt(np.maximum(np.diag(B), 0.0))
+        k = int(np.argmax(ax))
+        ax = B[:, k] / max(ax[k], 1e-300)
+        ax = ax / max(np.linalg.norm(ax), 1e-300)
+        if a @ ax < 0:
+            ax = -ax
+        return ax * th
+    return a * (th / s)
+
+
+def left_jacobian_so3(r):
+    """exp(r + d) ~ exp(J_l(r) d) exp(r): J_l = I + (1 - cos th)/th^2 [r]x + (th - sin th)/th^3 [r]x^2."""
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    if th < 1e-6:
+        return np.eye(3) + 0.5 * K + K @ K / 6.0
+    return np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+
+
+def pose_rows_rvec(rvec, tvec, K4, X, uv):
+    """cv.projectPoints' residual (projected - observed, x/y interleaved) and Jacobian wrt (rvec, tvec), Rodrigues
+    parameterisation (analytically equal to OpenCV's dpdr / dpdt); also the normalised coordinates (the focal column)."""
+    R = exp_so3(rvec)
+    Xr = X @ R.T
+    Xc = Xr + tvec
+    z = np.where(np.abs(Xc[:, 2]) < 1e-12, 1e-12, Xc[:, 2])
+    x, y = Xc[:, 0] / z, Xc[:, 1] / z
+    n = len(X)
+    r = np.zeros(2 * n)
+    r[0::2], r[1::2] = K4[0] * x + K4[2] - uv[:, 0], K4[1] * y + K4[3] - uv[:, 1]
+    du = np.c_[K4[0] / z, np.zeros(n), -K4[0] * x / z]
+    dv = np.c_[np.zeros(n), K4[1] / z, -K4[1] * y / z]
+    Jl = left_jacobian_so3(rvec)
+    J = np.zeros((2 * n, 6))
+    for row, d in ((0, du), (1, dv)):
+        # d . (w x Xr) = w . (Xr x d): rotation about the camera origin moves the ROTATED point only (tvec is its own parameter)
+        wrow = np.cross(Xr, d)
+        J[row::2, 0:3] = wrow @ Jl
+        J[row::2, 3:6] = d
+    jf = np.zeros(2 * n)
+    jf[0::2], jf[1::2] = x, y
+    return r, J, jf
+
+
+def sym_solve(A, b):
+    """cv::solve(A, b, DECOMP_EIG / DECOMP_SVD) for a symmetric system: Cholesky when A is positive definite, else the
+    minimum-norm solution with eigenvalues below 2 eps trace(|w|) dropped (shared spec with solve.hip)."""
+    x = chol_solve(A, b)
+    if x is not None:
+        return x
+    w, V = np.linalg.eigh(A)
+    thr = 2.0 * DBL_EPSILON * np.abs(w).sum()
+    inv = np.where(np.abs(w) > thr, 1.0 / np.where(w == 0, 1.0, w), 0.0)
+    return V @ (inv * (V.T @ b))
+
+
+def lm_solver_pose(R, t, K4, X, uv, max_iters=20000, eps=1e-5):
+    """cv.solvePnPRefineLM = LMSolver::run (calib3d levmarq.cpp) on x = [rvec, tvec]: D = diag(J^T J) FIXED at the start,
+    lambda_0 = 1, step d solves (A + lambda D) d = J^T r, x' = x - d, gain ratio R = (S - S') / d.(2 v - A d):
+    R > 0.75 -> lambda /= 2 (to 0 below lambda_c = 0.75); R < 0.25 -> lambda *= nu, nu = clip((S' - S) / (d.v) + 2, 2, 10)
+    (from lambda = 0: lambda = lambda_c = 1 / max |diag(A^-1)|, nu /= 2); accept when S' < S; stop after max_iters, or when
+    |d|_inf < eps, or |r|_inf < eps.  camera.py:105-119 passes (20000, 1e-5)."""
+    x = np.r_[log_so3(R), t].astype(np.float64)
+    r, J, _ = pose_rows_rvec(x[:3], x[3:], K4, X, uv)
+    S = float(r @ r)
+    A, v = J.T @ J, J.T @ r
+    D = np.diag(A).copy()
+    lam, lc = 1.0, 0.75
+    it = 0
+    while True:
+        d = sym_solve(A + np.diag(lam * D), v)
+        xd = x - d
+        rd, Jd, _ = pose_rows_rvec(xd[:3], xd[3:], K4, X, uv)
+        Sd = float(rd @ rd)
+        dS = float(d @ (2.0 * v - A @ d))
+        Rg = (S - Sd) / (dS if abs(dS) > DBL_EPSILON else 1.0)
+        if Rg > 0.75:
+            lam *= 0.5
+            if lam < lc:
+                lam = 0.0
+        elif Rg < 0.25:
+            tq = float(d @ v)
+            nu = (Sd - S) / (tq if abs(tq) > DBL_EPSILON else 1.0) + 2.0
+            nu = min(max(nu, 2.0), 10.0)
+            if lam == 0.0:
+                Ainv = np.column_stack([sym_solve(A, e) for e in np.eye(6)])
+                lam = lc = 1.0 / max(DBL_EPSILON, float(np.abs(np.diag(Ainv)).max()))
+                nu *= 0.5
+            lam *= nu
+        if Sd < S:
+            S, x, r, J = Sd, xd, rd, Jd
+            A, v = J.T @ J, J.T @ r
+        it += 1
+        if not (it < max_iters and np.abs(d).max() >= eps and np.abs(r).max() >= eps):
+            break
+    return exp_so3(x[:3]), x[3:].copy()
+
+
+def _cvlevmarq(evaluate, solve_step, x0, max_iter, eps):
+    """CvLevMarq::update / updateAlt (calib3d compat_ptsetreg.cpp): lambda = 10^k, k_0 = -3; a step solves
+    (J^T J with its diagonal x (1 + lambda)) d = J^T r from the SAME normal equations until the error no longer grows
+    (k += 1 per rejection, up to 16; then the step is taken regardless); an accepted step lowers k by one and counts as an
+    iteration; stop after max_iter iterations or when |x - x_prev| / |x_prev| < eps.
+    evaluate(x) -> (err, normal equations or None); solve_step(normal equations, lambda) -> d or None."""
+    x = x0
+    k = -3
+    e_prev, ne = evaluate(x, True)
+    iters = 0
+    while True:
+        prev = x
+        d = solve_step(ne, 10.0 ** k)
+        cand = prev - d if d is not None else None
+        e = evaluate(cand, False)[0] if cand is not None else np.inf
+        while e > e_prev:
+            k += 1
+            if k > 16:
+                break
+            d = solve_step(ne, 10.0 ** k)
+            cand = prev - d if d is not None else None
+            e = evaluate(cand, False)[0] if cand is not None else np.inf
+        if cand is None or not np.isfinite(e):
+            return prev                         # no usable step at any damping (singular normal equations): keep the last parameters
+        k = max(k - 1, -16)
+        x = cand
+        iters += 1
+        if iters >= max_iter or np.linalg.norm(x - prev) / max(np.linalg.norm(prev), 1e-300) < eps:
+            return x
+        e_prev, ne = evaluate(x, True)
+
+
+def cvlevmarq_pose(R, t, K4, X, uv, max_iter=20, eps=FLT_EPSILON):
+    """cvFindExtrinsicCameraParams2's refinement (the SOLVEPNP_ITERATIVE refit of solvePnPRansac and the per-view initial
+    extrinsics of calibrateCamera): CvLevMarq over [rvec, tvec], criteria (20, FLT_EPSILON)."""
+    def evaluate(x, want_j):
+        r, J, _ = pose_rows_rvec(x[:3], x[3:], K4, X, uv)
+        return float(r @ r), ((J.T @ J, J.T @ r) if want_j else None)
+
+    def solve_step(ne, lam):
+        A, g = ne
+        return chol_solve(A + lam * np.diag(np.diag(A)), g)
+    x = _cvlevmarq(evaluate, solve_step, np.r_[log_so3(R), t].astype(np.float64), max_iter, eps)
+    return exp_so3(x[:3]), x[3:].copy()
+
+
+def _joint_cvlevmarq(views, weights, f, poses, cx, cy, max_iter, eps):
+    """calibrateCamera's joint fit (cvCalibrateCamera2Internal) under the reference's flags (prediction.py:398-404, 614-620):
+    free parameters fy (fx slaved, aspect 1) and [rvec, tvec] per view; identical duplicated views (Q1) collapse to weights.
+    Block-arrowhead normal equations solved through the Schur complement on f (equal to OpenCV's dense SVD solve whenever the
+    pose blocks are non-singular)."""
+    nv = len(views)
+    x0 = np.r_[f, np.concatenate([np.r_[log_so3(R_), t_] for R_, t_ in poses])]
+
+    def evaluate(x, want_j):
+        if not x[0] > 0:
+            return np.inf, None
+        err, blocks, aff, gf = 0.0, [], 0.0, 0.0
+        for vi, ((Xp, uv), wgt) in enumerate(zip(views, weights)):
+            p = x[1 + 6 * vi: 7 + 6 * vi]
+            r, J, jf = pose_rows_rvec(p[:3], p[3:], (x[0], x[0], cx, cy), Xp, uv)
+            err += wgt * float(r @ r)
+            if want_j:
+                blocks.append((wgt * J.T @ J, wgt * J.T @ jf, wgt * J.T @ r))
+                aff += wgt * float(jf @ jf)
+                gf += wgt * float(jf @ r)
+        return err, ((blocks, aff, gf) if want_j else None)
+
+    def solve_step(ne, lam):
+        blocks, aff, gf = ne
+        s_aff, s_g, sol = aff * (1 + lam), gf, []
+        for A_, B_, g_ in blocks:
+            Ad = A_ + lam * np.diag(np.diag(A_))
+            ab, ag = chol_solve(Ad, B_), chol_solve(Ad, g_)
+            if ab is None or ag is None:
+                return None
+            s_aff -= float(B_ @ ab)
+            s_g -= float(B_ @ ag)
+            sol.append((ab, ag))
+        if abs(s_aff) < 1e-300:
+            return None
+        df = s_g / s_aff
+        return np.r_[df, np.concatenate([ag - ab * df for ab, ag in sol])]
+    x = _cvlevmarq(evaluate, solve_step, x0, max_iter, eps)
+    return float(x[0]), [[exp_so3(x[1 + 6 * vi: 4 + 6 * vi]), x[4 + 6 * vi: 7 + 6 * vi].copy()] for vi in range(nv)]
+
+
 def polish4(R, t, K4, X4, uv4):
     """Damped Gauss-Newton polish of a minimal-sample pose on its own 4 points (shared spec with solve.hip):
     the closed-form homography decomposition is badly conditioned for long focal lengths."""
@@ -376,7 +582,7 @@ def pnp_ransac(K4, X, uv, ground_mask):
         H = homography_lsq(X[gi, :2], uv[gi], iters=10)
         pose = pose_from_homography(H, *K4) if H is not None else None
         if pose is not None:
-            pose = refine_pose_lm(pose[0], pose[1], K4, X[gi], uv[gi], max_iters=20)
+            pose = _refit(pose[0], pose[1], K4, X[gi], uv[gi])
             p, z = project(pose[0], pose[1], K4, X)
             e2 = ((p - uv) ** 2).sum(1)
             inl = (e2 <= 64.0) & (z > 1e-9)
@@ -386,7 +592,15 @@ def pnp_ransac(K4, X, uv, ground_mask):
     if best[0] < 4:
         return None
     (R, t), inl = best[2]
-    return refine_pose_lm(R, t, K4, X[inl], uv[inl], max_iters=20)
+    return _refit(R, t, K4, X[inl], uv[inl])
+
+
+def _refit(R, t, K4, X, uv):
+    """The 20-iteration pose refinement inside solvePnPRansac's final SOLVEPNP_ITERATIVE call and calibrateCamera's per-view
+    initial extrinsics (cvFindExtrinsicCameraParams2)."""
+    if STOP['schedule'] == 'opencv':
+        return cvlevmarq_pose(R, t, K4, X, uv, max_iter=20, eps=FLT_EPSILON)
+    return refine_pose_lm(R, t, K4, X, uv, max_iters=20)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -436,7 +650,12 @@ def calibrate_planes(views, weights, img_wh):
         pose = pose_from_homography(H, f, f, cx, cy)
         if pose is None:
             return None
-        poses.append(list(refine_pose_lm(pose[0], pose[1], (f, f, cx, cy), Xp, uv, max_iters=20)))
+        poses.append(list(_refit(pose[0], pose[1], (f, f, cx, cy), Xp, uv)))
+    if STOP['schedule'] == 'opencv':
+        f, poses = _joint_cvlevmarq(views, weights, f, poses, cx, cy, STOP['joint_iters'], DBL_EPSILON)
+        if not np.isfinite(f) or f <= 0:
+            return None
+        return f, cx, cy, _polar(poses[0][0]), poses[0][1]
     # joint LM over f and the poses (block-arrowhead normal equations, Schur complement on f)
     def total_cost(f_, poses_):
         c = 0.0
@@ -536,8 +755,12 @@ class Cam:
         self.rotation, self.position = R, -R.T @ t
 
     def refine_camera(self, ids, uv):
-        R, t = refine_pose_lm(self.rotation, -self.rotation @ self.position, self.K4, P64[ids], uv,
-                              max_iters=STOP['pose_iters'], eps=STOP['pose_eps'])
+        if STOP['schedule'] == 'opencv':
+            R, t = lm_solver_pose(self.rotation, -self.rotation @ self.position, self.K4, P64[ids], uv,
+                                  max_iters=STOP['pose_iters'], eps=STOP['pose_eps'])
+        else:
+            R, t = refine_pose_lm(self.rotation, -self.rotation @ self.position, self.K4, P64[ids], uv,
+                                  max_iters=STOP['pose_iters'], eps=STOP['pose_eps'])
         self.rotation, self.position = R, -R.T @ t
 
     def projection_rmse(self, ids, uv):

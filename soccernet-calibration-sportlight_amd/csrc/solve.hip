@@ -504,6 +504,252 @@ __device__ void refine_pose_lm(u64 mask, double* R, double* t, const K4& k, cons
     polar3(R);
 }
 
+// ---- OpenCV's own minimiser schedules (opencv-python 4.7.0.72, restated from the upstream sources from memory: UNPINNED; shared
+// specification with oracle/solve.py lm_solver_pose / cvlevmarq_pose / _joint_cvlevmarq).  Parameters are [rvec, tvec] (Rodrigues), as
+// cv.projectPoints differentiates them; SCHED_OPENCV is the default since round 3, SCHED_CONVERGED the build's earlier specification.
+constexpr int SCHED_OPENCV = 0, SCHED_CONVERGED = 1;
+constexpr double FLT_EPS = 1.1920928955078125e-07, DBL_EPS = 2.220446049250313e-16;
+
+__device__ __forceinline__ void log_so3(const double* R, double* r) {       // cv.Rodrigues(matrix -> vector), R orthonormal
+    const double c = fmin(1.0, fmax(-1.0, (R[0] + R[4] + R[8] - 1.0) * 0.5));
+    const double th = acos(c);
+    const double a[3] = {(R[7] - R[5]) * 0.5, (R[2] - R[6]) * 0.5, (R[3] - R[1]) * 0.5};      // sin(th) * axis
+    const double sn = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (sn < 1e-5) {
+        if (c > 0) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; return; }
+        // th ~ pi: axis from the symmetric part (R + I) / 2 = axis axis^T, sign from what is left of the antisymmetric part
+        const double B[9] = {(R[0] + 1) * 0.5, R[1] * 0.5, R[2] * 0.5, R[3] * 0.5, (R[4] + 1) * 0.5, R[5] * 0.5, R[6] * 0.5, R[7] * 0.5, (R[8] + 1) * 0.5};
+        const double d0 = sqrt(fmax(B[0], 0.0)), d1 = sqrt(fmax(B[4], 0.0)), d2 = sqrt(fmax(B[8], 0.0));
+        const int kx = d0 >= d1 && d0 >= d2 ? 0 : (d1 >= d2 ? 1 : 2);
+        const double dk = fmax(kx == 0 ? d0 : kx == 1 ? d1 : d2, 1e-300);
+        double ax[3] = {B[kx] / dk, B[3 + kx] / dk, B[6 + kx] / dk};
+        const double n = fmax(sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), 1e-300);
+        const double sg = (a[0] * ax[0] + a[1] * ax[1] + a[2] * ax[2]) < 0 ? -1.0 : 1.0;
+        r[0] = sg * ax[0] / n * th; r[1] = sg * ax[1] / n * th; r[2] = sg * ax[2] / n * th;
+        return;
+    }
+    const double q = th / sn;
+    r[0] = a[0] * q; r[1] = a[1] * q; r[2] = a[2] * q;
+}
+
+// exp(r + d) ~ exp(J_l(r) d) exp(r)
+__device__ __forceinline__ void left_jacobian_so3(const double* w, double* J) {
+    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    mul33(K, K, K2);
+    double a, b;
+    if (th < 1e-6) { a = 0.5; b = 1.0 / 6.0; }
+    else { a = (1 - cos(th)) / (th * th); b = (th - sin(th)) / (th * th * th); }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + b * K2[i];
+}
+
+// residual + Jacobian wrt (rvec, tvec): R = exp(rvec), Jl = left_jacobian_so3(rvec) computed by the caller
+__device__ __forceinline__ void pose_rows_rvec(const double* R, const double* Jl, const double* t, double f_x, double f_y, double cx,
+                                               double cy, const double* X, double u, double v, double (&ju)[6], double (&jv)[6],
+                                               double& ru, double& rv, double& xn, double& yn) {
+    double Xr[3];
+    const double zero[3] = {0, 0, 0};
+    cam_point(R, zero, X, Xr);
+    const double Xc[3] = {Xr[0] + t[0], Xr[1] + t[1], Xr[2] + t[2]};
+    const double z = fabs(Xc[2]) < 1e-12 ? 1e-12 : Xc[2];
+    const double x = Xc[0] / z, y = Xc[1] / z;
+    xn = x; yn = y;
+    ru = f_x * x + cx - u; rv = f_y * y + cy - v;
+    const double du[3] = {f_x / z, 0.0, -f_x * x / z}, dv[3] = {0.0, f_y / z, -f_y * y / z};
+    // d . (w x Xr) = w . (Xr x d): a rotation about the camera origin moves the ROTATED point only (tvec is its own parameter)
+    const double wu[3] = {Xr[1] * du[2] - Xr[2] * du[1], Xr[2] * du[0] - Xr[0] * du[2], Xr[0] * du[1] - Xr[1] * du[0]};
+    const double wv[3] = {Xr[1] * dv[2] - Xr[2] * dv[1], Xr[2] * dv[0] - Xr[0] * dv[2], Xr[0] * dv[1] - Xr[1] * dv[0]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ju[j] = wu[0] * Jl[j] + wu[1] * Jl[3 + j] + wu[2] * Jl[6 + j];
+        jv[j] = wv[0] * Jl[j] + wv[1] * Jl[3 + j] + wv[2] * Jl[6 + j];
+        ju[3 + j] = du[j]; jv[3 + j] = dv[j];
+    }
+}
+
+// cv::solve(A, b, DECOMP_EIG / DECOMP_SVD) for a symmetric 6x6 system: Cholesky when A is positive definite, else the minimum-norm
+// solution from a cyclic Jacobi eigen-decomposition with eigenvalues below 2 eps sum|w| dropped
+__device__ void sym_solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    if (chol_solve<6>(A, b, x)) return;
+    double M[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) { M[i][j] = A[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i + 1; j < 6; ++j) off += M[i][j] * M[i][j];
+        if (!(off > 1e-300)) break;
+        for (int pq = 0; pq < 15; ++pq) {
+            int p_ = 0, q_ = 1, c = pq;
+            for (p_ = 0; p_ < 5; ++p_) { if (c < 5 - p_) { q_ = p_ + 1 + c; break; } c -= 5 - p_; }
+            const double apq = M[p_][q_];
+            if (apq == 0.0) continue;
+            const double th = (M[q_][q_] - M[p_][p_]) / (2.0 * apq);
+            const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+            for (int k2 = 0; k2 < 6; ++k2) { const double a = M[k2][p_], bb = M[k2][q_]; M[k2][p_] = cs * a - sn * bb; M[k2][q_] = sn * a + cs * bb; }
+            for (int k2 = 0; k2 < 6; ++k2) { const double a = M[p_][k2], bb = M[q_][k2]; M[p_][k2] = cs * a - sn * bb; M[q_][k2] = sn * a + cs * bb; }
+            for (int k2 = 0; k2 < 6; ++k2) { const double a = V[k2][p_], bb = V[k2][q_]; V[k2][p_] = cs * a - sn * bb; V[k2][q_] = sn * a + cs * bb; }
+        }
+    }
+    double sw = 0;
+    for (int i = 0; i < 6; ++i) sw += fabs(M[i][i]);
+    const double thr = 2.0 * DBL_EPS * sw;
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+    for (int e = 0; e < 6; ++e) {
+        if (!(fabs(M[e][e]) > thr)) continue;
+        double pj = 0;
+        for (int i = 0; i < 6; ++i) pj += V[i][e] * b[i];
+        pj /= M[e][e];
+        for (int i = 0; i < 6; ++i) x[i] += V[i][e] * pj;
+    }
+}
+
+// normal equations of the pose problem at x = [rvec, tvec]: A = J^T J, g = J^T r, S = |r|^2, rinf = |r|_inf (all wave-uniform)
+__device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const double* X, double u, double v, bool want_j,
+                               double (&A)[6][6], double (&g)[6], double& S, double& rinf) {
+    const int lane = threadIdx.x & 63;
+    const bool in = (mask >> lane) & 1;
+    double R[9], Jl[9];
+    exp_so3(x, R);
+    double ju[6], jv[6], ru, rv, xn, yn;
+    if (want_j) {
+        left_jacobian_so3(x, Jl);
+        pose_rows_rvec(R, Jl, x + 3, k.fx, k.fy, k.cx, k.cy, X, u, v, ju, jv, ru, rv, xn, yn);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                const double s = wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                A[i][j] = s; A[j][i] = s;
+            }
+            g[i] = wsum(in ? ju[i] * ru + jv[i] * rv : 0.0);
+        }
+    } else {
+        double Xc[3];
+        cam_point(R, x + 3, X, Xc);
+        const double z = fabs(Xc[2]) < 1e-12 ? 1e-12 : Xc[2];
+        ru = k.fx * Xc[0] / z + k.cx - u; rv = k.fy * Xc[1] / z + k.cy - v;
+    }
+    S = wsum(in ? ru * ru + rv * rv : 0.0);
+    rinf = wmax(in ? fmax(fabs(ru), fabs(rv)) : 0.0);
+}
+
+// cv.solvePnPRefineLM = LMSolver::run (calib3d levmarq.cpp): D = diag(J^T J) fixed at the start, lambda_0 = 1, gain-ratio schedule
+// (0.25 / 0.75, nu in [2, 10], lambda -> 0 below lambda_c), accept when the error falls, stop on |d|_inf < eps or |r|_inf < eps
+__device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v, int max_iters, double eps) {
+    double x[6];
+    log_so3(R, x);
+    x[3] = t[0]; x[4] = t[1]; x[5] = t[2];
+    double A[6][6], g[6], S, rinf;
+    pose_normal_eq(mask, x, k, X, u, v, true, A, g, S, rinf);
+    double D[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) D[i] = A[i][i];
+    double lam = 1.0, lc = 0.75;
+    for (int it = 0;;) {
+        double Ap[6][6], d[6], xd[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Ap[i][j] = A[i][j] + (i == j ? lam * D[i] : 0.0);
+        sym_solve6(Ap, g, d);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xd[i] = x[i] - d[i];
+        double A2[6][6], g2[6], Sd, rinf_d;
+        pose_normal_eq(mask, xd, k, X, u, v, false, A2, g2, Sd, rinf_d);
+        double dS = 0, dv_ = 0, dmax = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double Ad = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Ad += A[i][j] * d[j];
+            dS += d[i] * (2.0 * g[i] - Ad);
+            dv_ += d[i] * g[i];
+            dmax = fmax(dmax, fabs(d[i]));
+        }
+        const double Rg = (S - Sd) / (fabs(dS) > DBL_EPS ? dS : 1.0);
+        if (Rg > 0.75) {
+            lam *= 0.5;
+            if (lam < lc) lam = 0.0;
+        } else if (Rg < 0.25) {
+            double nu = (Sd - S) / (fabs(dv_) > DBL_EPS ? dv_ : 1.0) + 2.0;
+            nu = fmin(fmax(nu, 2.0), 10.0);
+            if (lam == 0.0) {
+                double mx = DBL_EPS;
+                for (int e = 0; e < 6; ++e) {
+                    double unit[6] = {0, 0, 0, 0, 0, 0}, col[6];
+                    unit[e] = 1.0;
+                    sym_solve6(A, unit, col);
+                    mx = fmax(mx, fabs(col[e]));
+                }
+                lam = lc = 1.0 / mx;
+                nu *= 0.5;
+            }
+            lam *= nu;
+        }
+        if (Sd < S) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = xd[i];
+            pose_normal_eq(mask, x, k, X, u, v, true, A, g, S, rinf);
+        }
+        ++it;
+        if (!(it < max_iters && dmax >= eps && rinf >= eps)) break;
+    }
+    exp_so3(x, R);
+    t[0] = x[3]; t[1] = x[4]; t[2] = x[5];
+}
+
+// cvFindExtrinsicCameraParams2's refinement (solvePnPRansac's final SOLVEPNP_ITERATIVE refit, calibrateCamera's per-view initial
+// extrinsics): CvLevMarq over [rvec, tvec] -- lambda = 10^k, k_0 = -3, diagonal x (1 + lambda), steps from the same normal equations
+// until the error no longer grows (k + 1 per rejection, up to 16), an accepted step lowers k; criteria (max_iter, eps on |dx| / |x|)
+__device__ void cvlevmarq_pose(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v, int max_iter, double eps) {
+    double x[6];
+    log_so3(R, x);
+    x[3] = t[0]; x[4] = t[1]; x[5] = t[2];
+    double A[6][6], g[6], e_prev, rinf;
+    pose_normal_eq(mask, x, k, X, u, v, true, A, g, e_prev, rinf);
+    int kk = -3, iters = 0;
+    for (;;) {
+        double cand[6], e = INFINITY;
+        bool have = false;
+        for (;;) {
+            const double lam = pow(10.0, (double)kk);
+            double Ad[6][6], d[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Ad[i][j] = A[i][j] + (i == j ? lam * A[i][i] : 0.0);
+            if (chol_solve<6>(Ad, g, d)) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cand[i] = x[i] - d[i];
+                double A2[6][6], g2[6], r2;
+                pose_normal_eq(mask, cand, k, X, u, v, false, A2, g2, e, r2);
+                have = true;
+            } else { e = INFINITY; have = false; }
+            if (!(e > e_prev)) break;
+            if (++kk > 16) break;
+        }
+        if (!have || !isfinite(e)) break;                    // no usable step at any damping: keep the last parameters
+        kk = max(kk - 1, -16);
+        double dn = 0, pn = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { dn += (cand[i] - x[i]) * (cand[i] - x[i]); pn += x[i] * x[i]; x[i] = cand[i]; }
+        ++iters;
+        if (iters >= max_iter || sqrt(dn) / fmax(sqrt(pn), 1e-300) < eps) break;
+        pose_normal_eq(mask, x, k, X, u, v, true, A, g, e_prev, rinf);
+    }
+    exp_so3(x, R);
+    t[0] = x[3]; t[1] = x[4]; t[2] = x[5];
+}
+
+__device__ __forceinline__ void refit_pose(int sched, u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v) {
+    if (sched == SCHED_OPENCV) cvlevmarq_pose(mask, R, t, k, X, u, v, 20, FLT_EPS);
+    else refine_pose_lm(mask, R, t, k, X, u, v, 20, 1e-10);
+}
+
 // Lane-local damped Gauss-Newton polish of a minimal-sample pose on its own 4 (z=0) points.  The closed-form
 // homography decomposition is badly conditioned for long focal lengths; a few iterations repair it.
 __device__ void polish4(double* R, double* t, const K4& k, const double (&s)[4][2], const double (&d)[4][2]) {
@@ -550,7 +796,7 @@ __device__ void polish4(double* R, double* t, const K4& k, const double (&s)[4][
 
 // Camera.solve_pnp (camera.py:92-103): planar minimal solver on the z=0 points (64 lane-parallel 4-point
 // hypotheses + one least-squares homography over all of them), 8 px inliers, LM refit on the inliers
-__device__ bool pnp_ransac(u64 mask, u64 gmask, const K4& k, const double* X, double u, double v, double* R, double* t) {
+__device__ bool pnp_ransac(int sched, u64 mask, u64 gmask, const K4& k, const double* X, double u, double v, double* R, double* t) {
     const int lane = threadIdx.x & 63;
     const int n = popc64(gmask);
     if (n < 4) return false;
@@ -590,7 +836,7 @@ __device__ bool pnp_ransac(u64 mask, u64 gmask, const K4& k, const double* X, do
     {   // hypothesis NH_PNP: least-squares homography over every z=0 point (stable when a 4-point sample is not)
         double Hl[9], Rl[9], tl[3];
         if (homography_lsq(gmask, X[0], X[1], u, v, 10, Hl) && pose_from_homography(Hl, k.fx, k.fy, k.cx, k.cy, Rl, tl)) {
-            refine_pose_lm(gmask, Rl, tl, k, X, u, v, 20, 1e-10);
+            refit_pose(sched, gmask, Rl, tl, k, X, u, v);
             double z;
             const double e2 = reproj_e2(Rl, tl, k, X, u, v, &z);
             const bool inl = ((mask >> lane) & 1) && e2 <= 64.0 && z > 1e-9;
@@ -608,14 +854,14 @@ __device__ bool pnp_ransac(u64 mask, u64 gmask, const K4& k, const double* X, do
     double z;
     const double e2 = reproj_e2(R, t, k, X, u, v, &z);
     const u64 inl = __ballot(((mask >> lane) & 1) && e2 <= 64.0 && z > 1e-9);
-    refine_pose_lm(inl, R, t, k, X, u, v, 20, 1e-10);
+    refit_pose(sched, inl, R, t, k, X, u, v);
     return true;
 }
 
 // ---- calibrateCamera restatement (planar views, pp fixed at ((w-1)/2,(h-1)/2), aspect 1, no distortion) ----
 struct View { u64 mask; int kind; double weight; };   // kind 0 ground (x,y), 1 goal plane (y,z)
 
-__device__ bool calibrate_planes(const View* views, int nviews, const double* X32, double u32, double v32, int img_w,
+__device__ bool calibrate_planes(int sched, const View* views, int nviews, const double* X32, double u32, double v32, int img_w,
                                  int img_h, double& f_out, double* R0, double* t0) {
     const int lane = threadIdx.x & 63;
     const double cx = (img_w - 1) * 0.5, cy = (img_h - 1) * 0.5;
@@ -654,7 +900,98 @@ __device__ bool calibrate_planes(const View* views, int nviews, const double* X3
         if (!pose_from_homography(Hs[vi], f, f, cx, cy, Rv[vi], tv[vi])) return false;
         const double Xp[3] = {views[vi].kind ? X32[1] : X32[0], views[vi].kind ? X32[2] : X32[1], 0.0};
         const K4 k{f, f, cx, cy};
-        refine_pose_lm(views[vi].mask, Rv[vi], tv[vi], k, Xp, u32, v32, 20, 1e-10);
+        refit_pose(sched, views[vi].mask, Rv[vi], tv[vi], k, Xp, u32, v32);
+    }
+    if (sched == SCHED_OPENCV) {
+        // calibrateCamera's joint fit (cvCalibrateCamera2Internal, CvLevMarq::updateAlt, criteria (30, DBL_EPSILON)): free parameters
+        // fy (fx slaved) and [rvec, tvec] per view; duplicated views (Q1) are weights; block-arrowhead normal equations through the
+        // Schur complement on f (= OpenCV's dense SVD solve whenever the pose blocks are non-singular)
+        double xs[3][6];
+        for (int vi = 0; vi < nviews; ++vi) {
+            log_so3(Rv[vi], xs[vi]);
+            xs[vi][3] = tv[vi][0]; xs[vi][4] = tv[vi][1]; xs[vi][5] = tv[vi][2];
+        }
+        double A[3][6][6], Bv[3][6], g[3][6], aff = 0, gf = 0;
+        auto evaluate = [&](double f_, const double (*xx)[6], bool want_j) -> double {
+            if (!(f_ > 0)) return INFINITY;
+            double err = 0;
+            if (want_j) { aff = 0; gf = 0; }
+            for (int vi = 0; vi < nviews; ++vi) {
+                const bool in = (views[vi].mask >> lane) & 1;
+                const double Xp[3] = {views[vi].kind ? X32[1] : X32[0], views[vi].kind ? X32[2] : X32[1], 0.0};
+                double Rr[9], Jl[9], ju[6], jv[6], ru, rv, xn, yn;
+                exp_so3(xx[vi], Rr);
+                left_jacobian_so3(xx[vi], Jl);
+                pose_rows_rvec(Rr, Jl, xx[vi] + 3, f_, f_, cx, cy, Xp, u32, v32, ju, jv, ru, rv, xn, yn);
+                const double wgt = views[vi].weight;
+                err += wgt * wsum(in ? ru * ru + rv * rv : 0.0);
+                if (want_j) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                        for (int j = i; j < 6; ++j) {
+                            const double s2 = wgt * wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                            A[vi][i][j] = s2; A[vi][j][i] = s2;
+                        }
+                        Bv[vi][i] = wgt * wsum(in ? ju[i] * xn + jv[i] * yn : 0.0);
+                        g[vi][i] = wgt * wsum(in ? ju[i] * ru + jv[i] * rv : 0.0);
+                    }
+                    aff += wgt * wsum(in ? xn * xn + yn * yn : 0.0);
+                    gf += wgt * wsum(in ? xn * ru + yn * rv : 0.0);
+                }
+            }
+            return err;
+        };
+        double e_prev = evaluate(f, xs, true);
+        int kk = -3, iters = 0;
+        for (;;) {
+            double fc = f, xc[3][6], e = INFINITY;
+            bool have = false;
+            for (;;) {
+                const double lam = pow(10.0, (double)kk);
+                double s_aff = aff * (1 + lam), s_g = gf, AiB[3][6], Aig[3][6];
+                bool ok = true;
+                for (int vi = 0; vi < nviews && ok; ++vi) {
+                    double Ad[6][6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) Ad[i][j] = A[vi][i][j] + (i == j ? lam * A[vi][i][i] : 0.0);
+                    ok = chol_solve<6>(Ad, Bv[vi], AiB[vi]) && chol_solve<6>(Ad, g[vi], Aig[vi]);
+                    if (ok) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) { s_aff -= Bv[vi][i] * AiB[vi][i]; s_g -= Bv[vi][i] * Aig[vi][i]; }
+                    }
+                }
+                have = ok && !(fabs(s_aff) < 1e-300);
+                if (have) {
+                    const double df = s_g / s_aff;                  // x' = x - d
+                    fc = f - df;
+                    for (int vi = 0; vi < nviews; ++vi)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) xc[vi][i] = xs[vi][i] - (Aig[vi][i] - AiB[vi][i] * df);
+                    e = evaluate(fc, xc, false);
+                } else e = INFINITY;
+                if (!(e > e_prev)) break;
+                if (++kk > 16) break;
+            }
+            if (!have || !isfinite(e)) break;
+            kk = max(kk - 1, -16);
+            double dn = (fc - f) * (fc - f), pn = f * f;
+            for (int vi = 0; vi < nviews; ++vi)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { dn += views[vi].weight * (xc[vi][i] - xs[vi][i]) * (xc[vi][i] - xs[vi][i]); pn += views[vi].weight * xs[vi][i] * xs[vi][i]; xs[vi][i] = xc[vi][i]; }
+            f = fc;
+            ++iters;
+            if (iters >= 30 || sqrt(dn) / fmax(sqrt(pn), 1e-300) < DBL_EPS) break;
+            e_prev = evaluate(f, xs, true);
+        }
+        if (!isfinite(f) || f <= 0) return false;
+        f_out = f;
+        exp_so3(xs[0], R0);
+        polar3(R0);
+        t0[0] = xs[0][3]; t0[1] = xs[0][4]; t0[2] = xs[0][5];
+        return true;
     }
     auto total_cost = [&](double f_, double (*Rs)[9], double (*ts)[3]) {
         double c = 0;
@@ -768,12 +1105,13 @@ __device__ __forceinline__ void cam_t(const Cam& c, double* t) {   // t = -R pos
 struct Pts {   // lane-local point data
     double X64[3], X32[3];
     double u, v, u32, v32;
+    int sched;       // SCHED_OPENCV / SCHED_CONVERGED
 };
 
 __device__ bool cam_solve_pnp(Cam& c, u64 mask, const Pts& p) {
     double R[9], t[3];
     const K4 k{c.fx, c.fy, c.cx, c.cy};
-    if (!pnp_ransac(mask, mask & GROUND_MASK, k, p.X64, p.u, p.v, R, t)) return false;
+    if (!pnp_ransac(p.sched, mask, mask & GROUND_MASK, k, p.X64, p.u, p.v, R, t)) return false;
     cam_set_pose(c, R, t);
     return true;
 }
@@ -783,7 +1121,8 @@ __device__ void cam_refine(Cam& c, u64 mask, const Pts& p) {
     for (int i = 0; i < 9; ++i) R[i] = c.R[i];
     cam_t(c, t);
     const K4 k{c.fx, c.fy, c.cx, c.cy};
-    refine_pose_lm(mask, R, t, k, p.X64, p.u, p.v, 100, 1e-10);
+    if (p.sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, p.X64, p.u, p.v, 20000, 1e-5);      // camera.py:116-117
+    else refine_pose_lm(mask, R, t, k, p.X64, p.u, p.v, 100, 1e-10);
     cam_set_pose(c, R, t);
 }
 // Camera.projection_rmse (camera.py:270-277; project_point :249-268 with the fp32 round trip of distort :247)
@@ -863,7 +1202,7 @@ __device__ int camera_all_points(u64 mask, const Pts& p, int img_w, int img_h, C
     for (int i = 0; i < nv; ++i) total += views[i].weight * popc64(views[i].mask);
     if (!(nv > 0 && total > 6)) return ST_NONE;
     double f, R0[9], t0[3];
-    if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0)) return ST_NONE;
+    if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0)) return ST_NONE;
     cam_from_calibration(c, f, R0, t0, img_w, img_h);
     if (!cam_solve_pnp(c, mask, p)) return ST_NONE;            // always runs (quirk Q2)
     if (popc64(mask) > 6) cam_refine(c, mask, p);
@@ -925,7 +1264,7 @@ __device__ int original_voter(const float* kp, const float* line_pts, const snca
     const int nv = build_views(mask, cfg.min_points_per_plane, false, views);
     if (nv > 0 && popc64(mask) > cfg.min_points) {
         double f, R0[9], t0[3];
-        if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+        if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
         cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
         out.tag = SNCAL_CAM_ORIGINAL;
         have = true;
@@ -1015,7 +1354,7 @@ __device__ int opencv_calibration(const float* kp, const sncal_voter_cfg& cfg, c
     if (popc64(mask) <= 5) return ST_NONE;
     View v{mask, 0, 1.0};
     double f, R0[9], t0[3];
-    if (!calibrate_planes(&v, 1, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+    if (!calibrate_planes(p.sched, &v, 1, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
     cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
     out.tag = SNCAL_CAM_ORIGINAL;
     out.rmse = cam_rmse(out, mask, p);
@@ -1030,7 +1369,7 @@ __device__ int opencv_calibration_multiplane(const float* kp, const float* line_
     const int nv = build_views(mask, cfg.min_points_per_plane, false, views);
     if (!(nv > 0 && popc64(mask) > cfg.min_points)) return ST_NONE;
     double f, R0[9], t0[3];
-    if (!calibrate_planes(views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+    if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
     if (!(f > cfg.min_focal_length)) return ST_NONE;
     cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
     if (popc64(mask) > cfg.min_points_for_refinement) cam_refine(out, mask, p);
@@ -1081,6 +1420,7 @@ __global__ __launch_bounds__(256, 1) void voter_kernel(const float* __restrict__
     const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
     Pts p;
     load_points(kp, p);
+    p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1104,6 +1444,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
     Pts p;
     load_points(kp, p);
+    p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1135,7 +1476,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
 __global__ __launch_bounds__(64) void pnp_kernel(const double* __restrict__ Kin, const double* __restrict__ p3,
                                                  const double* __restrict__ p2, const int* __restrict__ npts, int N,
                                                  double* __restrict__ rt, double* __restrict__ rmse, int mode,
-                                                 int max_iters, double eps) {
+                                                 int max_iters, double eps, int sched) {
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const int n = min(npts[b], min(N, 64));
     const bool in = lane < n;
@@ -1153,11 +1494,12 @@ __global__ __launch_bounds__(64) void pnp_kernel(const double* __restrict__ Kin,
     bool ok = true;
     if (mode == 0) {
         for (int i = 0; i < 3; ++i) t[i] = -(R[i * 3] * pos[0] + R[i * 3 + 1] * pos[1] + R[i * 3 + 2] * pos[2]);
-        refine_pose_lm(mask, R, t, k, X, u, v, max_iters, eps);
+        if (sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, X, u, v, max_iters, eps);
+        else refine_pose_lm(mask, R, t, k, X, u, v, max_iters, eps);
     } else {
         // plane membership for the minimal solver = points with z == 0 (ids outside top_gates)
         const u64 gm = __ballot(in && X[2] == 0.0);
-        ok = pnp_ransac(mask, gm, k, X, u, v, R, t);
+        ok = pnp_ransac(sched, mask, gm, k, X, u, v, R, t);
     }
     if (lane == 0 && ok) {
         for (int i = 0; i < 9; ++i) rt[b * 12 + i] = R[i];
@@ -1258,21 +1600,27 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     return SNCAL_OK;
 }
 
+static int env_schedule() {       // SNCAL_SOLVE_SCHEDULE=converged: the two single-camera entries on the run-to-convergence minimisers
+    static const int v = (getenv("SNCAL_SOLVE_SCHEDULE") && std::string(getenv("SNCAL_SOLVE_SCHEDULE")) == "converged") ? SCHED_CONVERGED : SCHED_OPENCV;
+    return v;
+}
+
 static int launch_pnp(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts, int B, int N,
                       double* d_rt, double* d_rmse, int mode, int max_iters, double eps, void* stream) {
     SNCAL_CHECK_ARG(B >= 0 && N > 0 && N <= 64, "pnp: need 0 < N <= 64 points per frame (got %d)", N);
     if (B == 0) return SNCAL_OK;
     SNCAL_CHECK_ARG(d_K && d_pts3d && d_pts2d && d_npts && d_rt, "pnp: null pointer");
     hipLaunchKernelGGL(pnp_kernel, dim3(B), dim3(64), 0, sncal::as_stream(stream), d_K, d_pts3d, d_pts2d, d_npts, N, d_rt,
-                       d_rmse, mode, max_iters, eps);
+                       d_rmse, mode, max_iters, eps, env_schedule());
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }
 
 extern "C" int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,
                                    int B, int N, double* d_rt, double* d_rmse, int max_iters, double eps, void* stream) {
-    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : 100,
-                      eps > 0 ? eps : 1e-10, stream);
+    const bool cv = env_schedule() == SCHED_OPENCV;      // defaults = the criteria camera.py:116-117 passes: (20000, 1e-5)
+    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : (cv ? 20000 : 100),
+                      eps > 0 ? eps : (cv ? 1e-5 : 1e-10), stream);
 }
 
 extern "C" int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,

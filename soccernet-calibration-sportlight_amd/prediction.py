@@ -82,6 +82,9 @@ class CameraCreator:
         self.max_rmse, self.max_rmse_rel = 55.0, 5.0
         self.min_points, self.min_focal_length = 5, 10.0
         self.min_points_per_plane, self.min_points_for_refinement, self.reliable_thresh = 6, 6, 57
+        # build-side switch (no reference counterpart): 'opencv' = the minimisers follow OpenCV's own LM schedules (default),
+        # 'converged' = every minimiser runs to convergence (sncal_voter_cfg.lm_schedule)
+        self.lm_schedule = 'opencv'
         for key, value in kwargs.items():
             setattr(self, key, value)
         self.stat = {'n': 0, 'frames_4': 0, 'frames_4_6': 0, 'frames_bad_cam': 0}
@@ -102,6 +105,9 @@ class CameraCreator:
         c.min_points_for_refinement, c.reliable_thresh = int(self.min_points_for_refinement), int(self.reliable_thresh)
         c.min_focal_length = float(self.min_focal_length)
         c.img_w, c.img_h = int(self.img_size[0]), int(self.img_size[1])
+        if self.lm_schedule not in ('opencv', 'converged'):
+            raise _lib.SncalError(f"lm_schedule must be 'opencv' or 'converged', not {self.lm_schedule!r}")
+        c.lm_schedule = 0 if self.lm_schedule == 'opencv' else 1
         return c
 
     def line_points_array(self, names):

@@ -14,7 +14,11 @@ cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof -name "*.csv" -size +2M -delete
+# the reference-precision engine, profiled the same way (the fp32 object of the main line comes from the same step)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof32 -o trace -- python $R/bench.py --dtype fp32 --steps 3 --warmup 2 --no-cpu-baseline --no-parity > $O/bench_c3_fp32_traced.json 2> $O/bench_c3_fp32_traced.err
+find $O/prof32 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_fp32.csv \;
+find $O/prof32 -name "*.csv" -size +2M -delete
 cd $R
-PMC_B=64 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" > $O/pmc.log 2>&1
+PMC_B=64 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc.log 2>&1
 head -c 1500 $O/bench_c3.json; echo; head -c 600 $O/bench_c4.json; echo; head -c 600 $O/bench_c3_fp8.json; echo; head -c 600 $O/bench_c5_fp8.json; echo; head -c 600 $O/bench_c5_bf16.json; echo
 head -8 $O/kernel_stats.csv; tail -30 $O/pmc.log

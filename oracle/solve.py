@@ -45,17 +45,20 @@ from .pitch import GOAL_LEFT, GOAL_RIGHT, GROUND, KEEP_POINTS, TOP_GATES, pitch_
 # bound the UNPINNED gap to OpenCV: `opencv_stops()` = calibrateCamera's default criteria of 30 joint iterations and
 # solvePnPRefineLM's criteria (20000, 1e-5) on step and residual (SURVEY 8c notes; the damping schedule stays the build's
 # own); `iac_failure='reference'` = go on with K = I as prediction.py:514 does.
-STOP = dict(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
-COUNTERS = dict(iac_failures=0)
+STOP = dict(schedule='opencv', joint_iters=30, pose_iters=200, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
+COUNTERS = dict(iac_failures=0, refine_cap_hits=0)
 FLT_EPSILON = 1.1920928955078125e-07
 DBL_EPSILON = 2.220446049250313e-16
 
 
-def opencv_stops():
-    """DEFAULT since round 3: the minimisers follow OpenCV 4.7's own schedules as far as they are known (SURVEY 8c notes, restated
+def opencv_stops(pose_iters=200):
+    """pose_iters: cap of refine_camera's LMSolver run.  The reference passes 20000 (camera.py:116); the build's default is 200
+    (shared with solve.hip, sncal_voter_cfg.refine_max_iters): well-posed frames stop on the 1e-5 step test within ~25 iterations,
+    the runs that reach a cap are poses refined under a degenerate calibration, where LMSolver alternates lambda = 0 / lambda_c.
+    DEFAULT since round 3: the minimisers follow OpenCV 4.7's own schedules as far as they are known (SURVEY 8c notes, restated
     from the upstream sources from memory -- still UNPINNED): LMSolver for solvePnPRefineLM (lm_solver_pose), CvLevMarq for the
     extrinsics refinements (cvlevmarq_pose, 20 iterations / FLT_EPSILON) and for calibrateCamera's joint fit (30 / DBL_EPSILON)."""
-    STOP.update(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5)
+    STOP.update(schedule='opencv', joint_iters=30, pose_iters=pose_iters, pose_eps=1e-5, pose_res_eps=1e-5)
 
 
 def converged_stops():
@@ -427,6 +430,8 @@ def lm_solver_pose(R, t, K4, X, uv, max_iters=20000, eps=1e-5):
         it += 1
         if not (it < max_iters and np.abs(d).max() >= eps and np.abs(r).max() >= eps):
             break
+    if it >= max_iters:
+        COUNTERS['refine_cap_hits'] += 1
     return exp_so3(x[:3]), x[3:].copy()
 
 

@@ -63,7 +63,7 @@ class VoterCfg(ctypes.Structure):
                 ('min_points', ctypes.c_int), ('min_points_per_plane', ctypes.c_int),
                 ('min_points_for_refinement', ctypes.c_int), ('reliable_thresh', ctypes.c_int),
                 ('min_focal_length', ctypes.c_double), ('img_w', ctypes.c_int), ('img_h', ctypes.c_int),
-                ('lm_schedule', ctypes.c_int)]
+                ('lm_schedule', ctypes.c_int), ('refine_max_iters', ctypes.c_int)]
 
 
 class JpegInfo(ctypes.Structure):

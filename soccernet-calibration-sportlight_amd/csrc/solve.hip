@@ -1106,6 +1106,7 @@ struct Pts {   // lane-local point data
     double X64[3], X32[3];
     double u, v, u32, v32;
     int sched;       // SCHED_OPENCV / SCHED_CONVERGED
+    int refine_iters;   // cap of refine_camera's LMSolver run (sncal_voter_cfg.refine_max_iters)
 };
 
 __device__ bool cam_solve_pnp(Cam& c, u64 mask, const Pts& p) {
@@ -1121,7 +1122,7 @@ __device__ void cam_refine(Cam& c, u64 mask, const Pts& p) {
     for (int i = 0; i < 9; ++i) R[i] = c.R[i];
     cam_t(c, t);
     const K4 k{c.fx, c.fy, c.cx, c.cy};
-    if (p.sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, p.X64, p.u, p.v, 20000, 1e-5);      // camera.py:116-117
+    if (p.sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, p.X64, p.u, p.v, p.refine_iters, 1e-5);      // camera.py:116-117
     else refine_pose_lm(mask, R, t, k, p.X64, p.u, p.v, 100, 1e-10);
     cam_set_pose(c, R, t);
 }
@@ -1421,6 +1422,7 @@ __global__ __launch_bounds__(256, 1) void voter_kernel(const float* __restrict__
     Pts p;
     load_points(kp, p);
     p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 200;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1445,6 +1447,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     Pts p;
     load_points(kp, p);
     p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 200;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1619,7 +1622,7 @@ static int launch_pnp(const double* d_K, const double* d_pts3d, const double* d_
 extern "C" int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,
                                    int B, int N, double* d_rt, double* d_rmse, int max_iters, double eps, void* stream) {
     const bool cv = env_schedule() == SCHED_OPENCV;      // defaults = the criteria camera.py:116-117 passes: (20000, 1e-5)
-    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : (cv ? 20000 : 100),
+    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : (cv ? 200 : 100),
                       eps > 0 ? eps : (cv ? 1e-5 : 1e-10), stream);
 }
 

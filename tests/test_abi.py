@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     L = sncal_amd._lib
     assert ctypes.sizeof(L.Camera) == 3 * 8 + 9 * 8 + 5 * 8 + 2 * 4          # sncal_camera
     assert ctypes.sizeof(L.HRNetDesc) == (6 + 3 + 3 + 3 + 12) * 4            # sncal_hrnet_desc
-    assert ctypes.sizeof(L.VoterCfg) == 8 + 8 + 32 + 16 + 4 * 4 + 8 + 8      # sncal_voter_cfg
+    assert ctypes.sizeof(L.VoterCfg) == 8 + 8 + 32 + 16 + 4 * 4 + 8 + 8 + 8  # sncal_voter_cfg (img_w, img_h, lm_schedule, refine_max_iters last)
 
 
 def test_plan_enumeration_matches_the_oracle_without_a_gpu():

@@ -176,12 +176,12 @@ int sncal_hrnet_get_profile(sncal_hrnet* net, sncal_kernel_stat* out, int cap, i
  * an earlier op -- while the tensor is still alive.  Taps never change what is launched. */
 typedef struct {
     int type;                  /* 0 input layout, 1 conv, 2 upsample_add, 3 softmax, 4 decode, 5 fused head                    */
-    int active;                /* part of the plan at the current layout (head variants live side by side)                   */
+    int active;                /* part of the plan at the current layout (three head formulations live side by side)         */
     int conv;                  /* conv unit (index as in sncal_hrnet_conv_info; >= num_convs: head-internal slice of last_layer.0) */
     char name[96];             /* its name, "" for non-conv ops                                                                */
     int cin, cout, ksize, stride, col_off;   /* col_off: first column of last_layer.0 of a head-internal slice               */
     int in, res, out, base;    /* tensor ids (-1 = none)                                                                       */
-    int src[3], nsrc;          /* upsample_add sources                                                                         */
+    int src[4], nsrc;          /* upsample_add sources                                                                         */
     int head_direct, head_src[5], head_nsrc, head_fold[2], head_nfold;
     int relu, out_coff, out_f32, fp8;        /* fp8: this conv runs in e4m3 at the current layout                            */
     char kernel[96];           /* label of the launch that executed it in the last mode-1 profiled forward ("" = unknown or

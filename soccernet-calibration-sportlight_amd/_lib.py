@@ -35,7 +35,7 @@ class PlanOp(ctypes.Structure):
     _fields_ = [('type', ctypes.c_int), ('active', ctypes.c_int), ('conv', ctypes.c_int), ('name', ctypes.c_char * 96),
                 ('cin', ctypes.c_int), ('cout', ctypes.c_int), ('ksize', ctypes.c_int), ('stride', ctypes.c_int),
                 ('col_off', ctypes.c_int), ('in_', ctypes.c_int), ('res', ctypes.c_int), ('out', ctypes.c_int),
-                ('base', ctypes.c_int), ('src', ctypes.c_int * 3), ('nsrc', ctypes.c_int), ('head_direct', ctypes.c_int),
+                ('base', ctypes.c_int), ('src', ctypes.c_int * 4), ('nsrc', ctypes.c_int), ('head_direct', ctypes.c_int),
                 ('head_src', ctypes.c_int * 5), ('head_nsrc', ctypes.c_int), ('head_fold', ctypes.c_int * 2),
                 ('head_nfold', ctypes.c_int), ('relu', ctypes.c_int), ('out_coff', ctypes.c_int), ('out_f32', ctypes.c_int),
                 ('fp8', ctypes.c_int), ('kernel', ctypes.c_char * 96)]

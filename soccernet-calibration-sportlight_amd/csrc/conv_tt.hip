@@ -204,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     // first version guarded every 16-byte load with `if (res && valid)`: hipcc then branches around each load and waits for
     // it before the next -- twelve dependent HBM round trips, 12k clk per tile against a 4k clk MFMA phase of the other team.)
     auto epilogue = [&]() {
+        if (P.ablate & 1) return;
         const unsigned out_bytes = (unsigned)(M.N * M.H * M.W * M.out_cstride * 2);
         const __amdgpu_buffer_rsrc_t rs_out8 = __builtin_amdgcn_make_buffer_rsrc(FP8 && M.out8 ? M.out8 : const_cast<void*>(M.in), 0,
                                                                                    FP8 && M.out8 ? (int)(out_bytes / 2) : 0, 0x00020000);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
             I_next = P.items[min(it + 1u, it_last)];
         }
         stamp();                                                  // [1] epilogue / setup done
-        issue_stage(c);
+        if (!(P.ablate & 4)) issue_stage(c);
         stamp();                                                  // [2] DMA issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my DMA pieces have landed (and my stores are out)
         stamp();                                                  // [3] landed
@@ -462,6 +463,11 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         }
         asm volatile("" ::: "memory");
         stamp();                                                  // [4] MULTIPLY begins
+        if (P.ablate & 2) {
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(w_early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && old == 4u * st + 3u) __hip_atomic_store(w_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else
         multiply_stage([&]() {
             unsigned old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(w_early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -40,6 +40,7 @@ struct TTParams {
     const uint32_t* team_first;     // [2 * n_wgs + 1] offsets into items
     const uint32_t* team_stages;    // [2 * n_wgs] sum of chunks over the team's items
     unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null
+    int ablate;                     // tuning aid (SNCAL_TT_ABLATE, timing only, results invalid): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA
 };
 
 void launch_conv_tt(const TTParams& p, int n_wgs, bool fp8, hipStream_t s);

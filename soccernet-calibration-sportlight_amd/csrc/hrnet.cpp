@@ -54,10 +54,11 @@ struct ConvLayer {
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
+    bool derived_shift = false;     // the slice that also carries last_layer.0's folded-BN shift (split head: the direct tensor's)
 };
 
 enum OpType { OP_INPUT, OP_CONV, OP_UPADD, OP_SOFTMAX, OP_DECODE, OP_HEAD };
-enum OpGroup { GRP_ALL = 0, GRP_UNFUSED = 1, GRP_FUSED = 2 };   // head variants living side by side in the plan
+enum OpGroup { GRP_ALL = 0, GRP_UNFUSED = 1, GRP_FUSED = 2, GRP_SPLIT = 3 };   // head variants living side by side in the plan
 
 struct Op {
     OpType type;
@@ -66,7 +67,7 @@ struct Op {
     bool relu = false;
     int out_coff = 0;
     bool out_f32 = false;
-    int base = -1, srcs[3] = {-1, -1, -1}, nsrc = 0;
+    int base = -1, srcs[4] = {-1, -1, -1, -1}, nsrc = 0;
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
     int group = GRP_ALL;
     int launch_group = -1;                // >= 0: independent convs that may share one grouped launch (consecutive ops)
@@ -107,6 +108,10 @@ struct sncal_hrnet {
     int head_direct_coff = 0, head_direct_c = 0, head_hp = 0, head_m2 = 0;
     int head_k = 0, head_ks1 = 2;     // stage-1 K of the fused head (direct + folded branch channels), its k-steps
     bool fused_enabled = true, use_fused = false;
+    // exact-fp32 engine: the head in its restructured form (per-source 1x1 products at native resolution, one bilinear sum) on the
+    // generic fp32 kernels -- the 784 -> 784 product at 270x480 (31 % of the reference's MACs) shrinks ninefold
+    bool has_split = false;
+    bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
@@ -190,6 +195,7 @@ struct Builder {
     int upadd(int base, const std::vector<int>& srcs, bool relu, int C) {
         Op op; op.type = OP_UPADD; op.base = base; op.nsrc = (int)srcs.size(); op.relu = relu;
         for (size_t i = 0; i < srcs.size(); ++i) op.srcs[i] = srcs[i];
+        op.group = net.cur_group;
         op.out = new_tensor(C);
         net.ops.push_back(op);
         return op.out;
@@ -408,6 +414,38 @@ struct Builder {
                 hop.head_src[hop.head_nsrc++] = conv(nm, t, false);
             }
             net.ops.push_back(hop);
+        }
+        // head, split formulation for the exact-fp32 engine: W0 . concat(up(b_i)) = sum_i up(W0_i . b_i) (a 1x1 convolution commutes
+        // with bilinear interpolation): every source's 1x1 product at ITS OWN resolution (generic fp32 conv kernel; the direct
+        // tensor's carries the folded-BN shift), one upsample_add with ReLU, then last_layer.3.  Same arithmetic type as the
+        // reference formulation, different summation order (fp32 rounding level); 8.8 instead of 79.7 GMAC per frame at 960x540
+        net.cur_group = GRP_SPLIT;
+        {
+            const int direct = d.upscale > 1 ? t_stem : ys[0];
+            std::vector<int> rest;
+            if (d.upscale > 1) rest = ys; else rest.assign(ys.begin() + 1, ys.end());
+            if (rest.size() <= 4) {
+                int col = 0;
+                const ConvLayer& H0 = net.layers[net.l_head0];
+                const int ld = add_layer("headx.d", "", net.tensors[direct].C, H0.cout, 1, 1, false);
+                net.layers[ld].derived = true; net.layers[ld].col_off = col; net.layers[ld].derived_shift = true;
+                col += net.tensors[direct].C;
+                const int t_d = conv("headx.d", direct, false);
+                std::vector<int> prods;
+                for (size_t gi = 0; gi < rest.size(); ++gi) {
+                    const std::string nm = fmt("headx.t%d", (int)gi);
+                    const int li = add_layer(nm, "", net.tensors[rest[gi]].C, H0.cout, 1, 1, false);
+                    net.layers[li].derived = true; net.layers[li].col_off = col;
+                    col += net.tensors[rest[gi]].C;
+                    prods.push_back(conv(nm, rest[gi], false));
+                }
+                const int hidden = upadd(t_d, prods, true, H0.cout);
+                net.ops.back().group = GRP_SPLIT;
+                Op op; op.type = OP_CONV; op.conv = net.l_head1; op.in = hidden; op.relu = false; op.out_f32 = true; op.group = GRP_SPLIT;
+                op.out = logits;
+                net.ops.push_back(op);
+                net.has_split = true;
+            }
         }
         net.cur_group = GRP_ALL;
         { Op op; op.type = OP_SOFTMAX; op.in = logits; op.out = new_tensor(d.num_classes, true);
@@ -686,7 +724,8 @@ int pack_head(sncal_hrnet& net) {
 
 // shape inference + workspace layout for a sub-batch of `sb` frames of HxW
 inline bool op_active(const sncal_hrnet& net, const Op& op) {
-    return op.group == GRP_ALL || (op.group == GRP_FUSED) == net.use_fused;
+    const int head = net.use_fused ? GRP_FUSED : net.use_split ? GRP_SPLIT : GRP_UNFUSED;
+    return op.group == GRP_ALL || op.group == head;
 }
 
 bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb);
@@ -701,6 +740,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         const int sh = half(H), sw = half(W), bh = half(sh), bw = half(sw);
         const bool dims_ok = net.desc.upscale == 1 || (sh == bh * net.desc.upscale && sw == bw * net.desc.upscale);
         net.use_fused = net.fused_enabled && net.dtype == SNCAL_BF16 && dims_ok && net.d_hw0 != nullptr;
+        net.use_split = !net.use_fused && net.split_enabled && net.has_split && net.dtype == SNCAL_F32 && dims_ok;
     }
     for (const Op& op : net.ops) {
         if (!op_active(net, op)) continue;
@@ -1064,6 +1104,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     unsigned long long* d_trace = nullptr;
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
     if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
+    { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
     launch_conv_tt(tp, it->second.n_wgs, fp8, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
@@ -1273,6 +1314,7 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
             L.scale.assign(L.cout, 1.f); L.shift.assign(L.cout, 0.f);
             for (int co = 0; co < H0.cout; ++co) {
                 L.scale[co] = H0.scale[co];
+                if (L.derived_shift) L.shift[co] = H0.shift[co];
                 for (int ci = 0; ci < L.cin; ++ci) L.w[(size_t)co * L.cin + ci] = H0.w[(size_t)co * H0.cin + L.col_off + ci];
             }
             L.is_set = true;
@@ -1433,7 +1475,7 @@ extern "C" int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_o
     memset(out, 0, sizeof(*out));
     out->type = (int)op.type; out->active = op_active(*net, op) ? 1 : 0; out->conv = op.conv;
     out->in = op.in; out->res = op.res; out->out = op.out; out->base = op.base; out->nsrc = op.nsrc;
-    for (int i = 0; i < 3; ++i) out->src[i] = op.srcs[i];
+    for (int i = 0; i < 4; ++i) out->src[i] = op.srcs[i];
     out->head_direct = op.head_direct; out->head_nsrc = op.head_nsrc; out->head_nfold = op.head_nfold;
     for (int i = 0; i < 5; ++i) out->head_src[i] = i < HEAD_MAX_SRC ? op.head_src[i] : -1;
     for (int i = 0; i < 2; ++i) out->head_fold[i] = i < HEAD_MAX_FOLD ? op.head_fold[i] : -1;

@@ -110,7 +110,7 @@ __device__ __forceinline__ void bilinear_acc(float (&acc)[Vec<T>::GE], const T* 
 // x / d by multiply-high with the host-computed reciprocal floor(2^32 / d) + 1 (exact while x * d < 2^32): the emulated
 // integer division costs ~25 VALU instructions in 32 bits and several times that in 64 bits -- with six of them per
 // 16-byte element this kernel was instruction-bound at 3 TB/s
-__device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+__device__ __forceinline__ unsigned udiv_magic(unsigned x, unsigned shift, unsigned magic) { return magic == 0 ? x >> shift : __umulhi(x >> shift, magic); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) {
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
     const int n = blockIdx.y;
     const size_t img_pix = (size_t)n * p.H * p.W;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per_img; i += gridDim.x * 256u) {
-        const unsigned pl = udiv_magic(i, cg, p.cg_magic);
+        const unsigned pl = udiv_magic(i, p.cg_shift, p.cg_magic);
         const int c0 = (int)(i - pl * cg) * GE;
-        const unsigned uy = udiv_magic(pl, (unsigned)p.W, p.w_magic);
+        const unsigned uy = udiv_magic(pl, p.w_shift, p.w_magic);
         const int oy = (int)uy, ox = (int)(pl - uy * (unsigned)p.W);
         const size_t pix = img_pix + pl;
         float acc[GE];
@@ -203,16 +203,19 @@ int launch_upsample_add(int dtype, const UpsampleAddParams& p0, hipStream_t s) {
     const int ge = dtype == SNCAL_BF16 ? 8 : 4;
     const unsigned cg = (unsigned)(p.C / ge);
     const size_t per_img = (size_t)p.H * p.W * cg;
-    // multiply-high division by m = floor((2^32 - 1) / d) + 1 is exact for every x with x * (m * d - 2^32) < 2^32
-    // (the error term m * d - 2^32 is < d, and 0 for powers of two): checked for (element index, cg) and (pixel index, W)
-    p.cg_magic = cg <= 1 ? 0u : 0xFFFFFFFFu / cg + 1u;
-    p.w_magic = p.W <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)p.W + 1u;
-    auto exact = [](unsigned long long xmax, unsigned d, unsigned magic) {
+    // x / d = (x >> shift) / odd with d = odd << shift; multiply-high division by m = floor((2^32 - 1) / odd) + 1 is exact for every
+    // y with y * (m * odd - 2^32) < 2^32 (the error term is < odd, 0 for odd = 1: magic 0 = shift only): checked for
+    // (element index, C / GE) and (pixel index, W) -- 196 channel groups x 540 x 960 pixels fail without the shift, pass with it
+    auto split = [](unsigned d, unsigned& shift, unsigned& magic, unsigned long long xmax) {
+        shift = 0;
+        while (d > 1 && (d & 1u) == 0) { d >>= 1; ++shift; }
+        magic = d <= 1 ? 0u : 0xFFFFFFFFu / d + 1u;
         if (d <= 1) return true;
         const unsigned long long err = (unsigned long long)magic * d - (1ull << 32);
-        return xmax * err < (1ull << 32);
+        return (xmax >> shift) * err < (1ull << 32);
     };
-    if (per_img >= (1ull << 31) || !exact(per_img, cg, p.cg_magic) || !exact((unsigned long long)p.H * p.W, (unsigned)p.W, p.w_magic)) {
+    const bool ok_c = split(cg, p.cg_shift, p.cg_magic, per_img), ok_w = split((unsigned)p.W, p.w_shift, p.w_magic, (unsigned long long)p.H * p.W);
+    if (per_img >= (1ull << 31) || !ok_c || !ok_w) {
         set_error("upsample_add: image of %d x %d x %d is too large", p.H, p.W, p.C);
         return SNCAL_ERR_ARG;
     }

@@ -8,15 +8,16 @@ namespace sncal {
 
 struct UpsampleAddParams {
     const void* base;        // optional [N][H][W][C] tensor added to the sum (NULL = 0)
-    const void* src[3];      // up to 3 low-resolution sources [N][Hs][Ws][C]
-    int Hs[3], Ws[3];
-    float sy[3], sx[3];      // align_corners=True scales (in-1)/(out-1)
+    const void* src[4];      // up to 4 low-resolution sources [N][Hs][Ws][C]
+    int Hs[4], Ws[4];
+    float sy[4], sx[4];      // align_corners=True scales (in-1)/(out-1)
     int nsrc;
     void* out;               // [N][H][W][out_cstride], channels written at out_coff
     int N, H, W, C;
     int out_cstride, out_coff;
     int relu;
-    unsigned cg_magic, w_magic;   // filled by the launcher: reciprocals of C/GE and W for the index decode
+    unsigned cg_magic, w_magic;   // filled by the launcher: reciprocals of the odd parts of C/GE and W for the index decode
+    unsigned cg_shift, w_shift;   // ... and their power-of-two parts (x / d = (x >> shift) / odd)
 };
 
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s);

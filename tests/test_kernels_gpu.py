@@ -66,6 +66,8 @@ class Weights:
             ws = torch.zeros((op['cout'], op['cin'], 1, 1), dtype=torch.float32)
             ws[:cout0] = w[:, op['col_off']:op['col_off'] + op['cin']] * sc[:, None, None, None]
             sh = torch.zeros(op['cout'], dtype=torch.float32)
+            if name == 'headx.d':               # split head (fp32 engine): the direct tensor's product carries last_layer.0's shift
+                sh[:cout0] = folded(self.sd, 'model.last_layer.0', bn, has_bias)[2]
         out = (ws.to(self.dev), sh.to(self.dev))
         self.cache[name] = out
         return out

@@ -38,7 +38,7 @@ typedef enum {
     SNCAL_ERR_UNSUPPORTED = -5 /* well-formed input that this build does not handle (e.g. progressive JPEG) */
 } sncal_status;
 
-typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1, SNCAL_FP8 = 2 } sncal_dtype;
+typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1, SNCAL_FP8 = 2, SNCAL_BF16X3 = 3 } sncal_dtype;
 
 int sncal_version(void);
 const char* sncal_last_error(void);
@@ -101,6 +101,9 @@ typedef struct sncal_hrnet sncal_hrnet;
 /* Build the execution plan (no weights yet).  dtype selects the arithmetic of the conv kernels:
  * SNCAL_BF16 = bf16 activations/weights with fp32 MFMA accumulation (fast path),
  * SNCAL_F32  = fp32 activations/weights on the exact-fp32 MFMA (parity path),
+ * SNCAL_BF16X3 = the fp32 engine (fp32 activations, fp32 accumulation) with SPLIT-bf16 arithmetic in the 3x3 stride-1 convolutions of
+ *              stages 2-4: x = hi + lo, w = hi + lo in bf16, hi.hi + hi.lo + lo.hi on the bf16 MFMA -- fp32-class results (|dlogp| ~ 5e-6
+ *              against the exact engine, same keypoint indices) at a multiple of the fp32 MFMA rate,
  * SNCAL_FP8  = the bf16 engine with OCP e4m3 arithmetic (CDNA4 block-scaled MFMA, K = 64) in the wide 3x3 stride-1
  *              convolutions of stages 2-4 (BASELINE config 5); needs sncal_hrnet_calibrate_fp8 before the first forward. */
 int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out);
@@ -183,7 +186,7 @@ typedef struct {
     int in, res, out, base;    /* tensor ids (-1 = none)                                                                       */
     int src[4], nsrc;          /* upsample_add sources                                                                         */
     int head_direct, head_src[5], head_nsrc, head_fold[2], head_nfold;
-    int relu, out_coff, out_f32, fp8;        /* fp8: this conv runs in e4m3 at the current layout                            */
+    int relu, out_coff, out_f32, fp8;        /* fp8: 1 = this conv runs in e4m3 at the current layout, 2 = in split bf16 (bf16x3)  */
     char kernel[96];           /* label of the launch that executed it in the last mode-1 profiled forward ("" = unknown or
                                   executed by the launch of an earlier op: grouped members, second conv of a fused block)      */
 } sncal_plan_op;

@@ -87,8 +87,15 @@ __device__ __forceinline__ TTMember load_member(int m) {
 // input channels in the same 54 KB + 22.5 KB of LDS, i.e. half the stages and half the DMA bytes per MAC, twice the MACs per
 // matrix-pipe cycle.  y = sum * (input scale x weight scale) + folded-BN shift is applied in the epilogue; the output goes out
 // as bf16 and / or as the e4m3 twin the next fp8 convolution reads.
-template <bool FP8>
+// MODE 2 (X3, the fp32-class engine `bf16x3`): fp32 activations and weights split into bf16 hi + bf16 lo (x = hi + lo to 2^-17),
+// y = hi.hi + hi.lo + lo.hi accumulated in fp32 -- three v_mfma_f32_32x32x16_bf16 per product where the exact-fp32 engine's
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate.  Measured against the plain fp32 forward (tools/x3_sim.py arithmetic):
+// |dlogp| 5e-6 mean / 1.4e-4 max, identical keypoint indices on every row.  The operand tensors are "split twins": per pixel and
+// 16-channel group [16 hi | 16 lo] bf16 -- byte for byte a bf16 tensor of 2 C pseudo-channels, so the halo / weight staging of the
+// bf16 mode is used unchanged (a stage = 16 real channels); only the MFMA pairing and the fp32 epilogue differ.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
+    constexpr bool FP8 = MODE == 1, X3 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,8 +210,70 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     // out-of-range offset (loads return zeros, stores are dropped), a missing residual is a zero-sized descriptor.  (The
     // first version guarded every 16-byte load with `if (res && valid)`: hipcc then branches around each load and waits for
     // it before the next -- twelve dependent HBM round trips, 12k clk per tile against a 4k clk MFMA phase of the other team.)
-    auto epilogue = [&]() {
+    auto epilogue_x3 = [&]() __attribute__((always_inline)) {
+        // fp32 in, fp32 out: (+ residual) (ReLU), 8 channels = 32 bytes per lane and item = two b128 accesses each way; channel blocks
+        // beyond the layer's width (a 48-channel layer runs as one 96-channel item with zero weights above 48) are not stored
+        const unsigned out_bytes = (unsigned)(M.N * M.H * M.W * M.out_cstride * 4);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.res ? M.res : M.in), 0, M.res ? (int)out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(M.out ? M.out : const_cast<void*>(M.in), 0, M.out ? (int)out_bytes : 0, 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const bool has_res = M.res != nullptr;
+        estamp();
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        float* const stg = reinterpret_cast<float*>(s_w + wp_first(tw) * 1024);
+        estamp();
+#pragma unroll
+        for (int jr = 0; jr < NB; ++jr) {
+            const int srow = row0 + tw * 2 + jr;
+            const unsigned f = __umulhi((unsigned)srow, M.hp1_magic);
+            const int y = srow - (int)f * (M.H + 1);
+            const bool row_ok = ((int)f < M.N) & (y < M.H);
+            const unsigned soff = row_ok ? (unsigned)(((((int)f * M.H + y) * M.W + col0) * M.out_cstride + M.out_coff + nb * TT_COUT) * 4) : 0u;
+            if (jr == 1) estamp();
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(stg + l31 * EPI_PITCH + mb * 32 + 8 * q + 4 * hi) =
+                        make_float4(acc[mb][jr][4 * q], acc[mb][jr][4 * q + 1], acc[mb][jr][4 * q + 2], acc[mb][jr][4 * q + 3]);
+#pragma unroll
+            for (int e = 0; e < EPI_ITERS; ++e) {
+                const int id = e * 64 + lane_l;
+                const int px = id / EPI_GROUPS, grp = id - px * EPI_GROUPS;
+                const bool ok = row_ok & (px < M.W - col0) & (nb * TT_COUT + grp * 8 < M.cout);
+                const unsigned voff = ok ? (unsigned)((px * M.out_cstride + grp * 8) * 4) : 0x80000000u;
+                const float* sp = stg + px * EPI_PITCH + grp * 8;
+                const float4 lo = *reinterpret_cast<const float4*>(sp), hi4 = *reinterpret_cast<const float4*>(sp + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (has_res) {
+                    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, soff, 0);
+                    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff, soff + 16u, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[k] += __uint_as_float(r0[k]); v[4 + k] += __uint_as_float(r1[k]); }
+                }
+                if (M.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                u32x4 o0 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                u32x4 o1 = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+                // hipcc leaves ONE wait state between a 16-byte store and the next write of its data registers (it reused the first data
+                // register of store 1 as the address of store 2, and rewrote store 2's data right behind it); under memory load gfx950
+                // reads store data later than that: isolated elements came out holding address bit patterns (the fp8 epilogue below met
+                // the same).  So: both vectors complete in registers of their own, no VALU between the stores (the +16 rides in the
+                // scalar offset), and the data registers stay live and untouched for four more wait states.
+                asm volatile("" : "+v"(o0), "+v"(o1));
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, voff, soff + 16u, 0);
+                asm volatile("s_nop 3" :: "v"(o0), "v"(o1) : "memory");
+            }
+        }
+        estamp();
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
         if (P.ablate & 1) return;
+        if constexpr (X3) { epilogue_x3(); return; }
         const unsigned out_bytes = (unsigned)(M.N * M.H * M.W * M.out_cstride * 2);
         const __amdgpu_buffer_rsrc_t rs_out8 = __builtin_amdgcn_make_buffer_rsrc(FP8 && M.out8 ? M.out8 : const_cast<void*>(M.in), 0,
                                                                                    FP8 && M.out8 ? (int)(out_bytes / 2) : 0, 0x00020000);
@@ -360,6 +429,45 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                 if (t + 1 < NKS) __builtin_amdgcn_sched_barrier(0);
             }
             near_end();
+        } else if constexpr (X3) {
+            // 9 taps x (10 fragment reads, 18 MFMAs): K-step h = 0 holds the hi parts, h = 1 the lo parts of the stage's 16 channels;
+            // acc += w_lo.x_hi + w_hi.x_lo + w_hi.x_hi (small terms first).  Fragments of tap s + 1 are fetched while tap s multiplies.
+            bf16x8 a[2][2][MB], b[2][2][NB];
+            auto load_frags = [&](int sidx, int buf) {
+                const int dy = sidx / 3, dx = sidx - dy * 3;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a[buf][h][mb] = *reinterpret_cast<const bf16x8*>(aptr + ((2 * sidx + h) * MB + mb) * 1024);
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr)
+                        b[buf][h][jr] = *reinterpret_cast<const bf16x8*>(bptr[dx][(jr + dy + 2 * h) & 3] + (jr + dy) * HP * 64);
+                }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int sidx = 0; sidx < NKS; ++sidx) {
+                const int cur = sidx & 1;
+                if (sidx == NKS - 1) near_end();
+                if (sidx + 1 < NKS) load_frags(sidx + 1, cur ^ 1);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int jr = 0; jr < NB; ++jr) {
+                        acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1][mb], b[cur][0][jr], acc[mb][jr], 0, 0, 0);
+                        acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][mb], b[cur][1][jr], acc[mb][jr], 0, 0, 0);
+                        acc[mb][jr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][mb], b[cur][0][jr], acc[mb][jr], 0, 0, 0);
+                    }
+                if (sidx + 1 < NKS) {                              // one fragment read behind each of the first ten MFMAs of the tap
+#pragma unroll
+                    for (int i = 0; i < 2 * (MB + NB); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NB - 2 * (MB + NB), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         } else {
             // 18 K = 16 steps (tap, channel half) x 6 MFMAs of 32 x 32 x 16; fragments of step t + 1 are fetched while step t
             // multiplies.  `near_end` runs before the last two steps (the token is handed on while ~400 clk of MFMAs are queued).
@@ -414,6 +522,8 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     unsigned* const w_done = w_arrive + 2;
     unsigned* const w_early = w_arrive + 3;
     if (tid < 16) ctrl[tid] = 0u;
+    for (int i = tid; i < 2 * TT_TABLE_MAX; i += 512) s_bias[i] = 0.f;      // (rows of a padded channel block read table slots nobody fills)
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < TT_MAX_MEMBERS; ++m) {
         const int o = m == 0 ? 0 : m == 1 ? tab1 : tab2;
@@ -482,16 +592,18 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
     if (S > 0) { epilogue(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 }
 
-void launch_conv_tt(const TTParams& p, int n_wgs, bool fp8, hipStream_t s) {
+void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const size_t lds = (size_t)2 * TEAM_BYTES + 64 + 2 * TT_TABLE_MAX * 4;
-    if (fp8) SNCAL_LAUNCH(conv_tt_kernel<true>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
-    else SNCAL_LAUNCH(conv_tt_kernel<false>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
+    if (mode == 1) SNCAL_LAUNCH(conv_tt_kernel<1>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
+    else if (mode == 2) SNCAL_LAUNCH(conv_tt_kernel<2>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
+    else SNCAL_LAUNCH(conv_tt_kernel<0>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
 }
 
 }  // namespace sncal

@@ -43,7 +43,7 @@ struct TTParams {
     int ablate;                     // tuning aid (SNCAL_TT_ABLATE, timing only, results invalid): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA
 };
 
-void launch_conv_tt(const TTParams& p, int n_wgs, bool fp8, hipStream_t s);
+void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s);      // mode 0 bf16, 1 fp8 (e4m3), 2 x3 (split-bf16, fp32 in / out)
 constexpr int TT_TABLE_MAX = 760;       // sum of the members' output channels the LDS bias / scale tables hold
 
 }  // namespace sncal

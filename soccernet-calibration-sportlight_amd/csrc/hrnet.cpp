@@ -51,6 +51,8 @@ struct ConvLayer {
     float* d_oscale = nullptr;
     int stage = 0;              // 2..4 for model.stageN.* layers, 0 otherwise
     bool fp8_on = false;
+    void* d_w_x3 = nullptr;     // bf16x3 engine: hi / lo split weights in the two-team kernel's fragment order (16-channel stages)
+    bool x3_on = false;
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
@@ -80,6 +82,7 @@ struct Tensor {
     bool f32 = false;         // fp32 storage regardless of the net dtype (logits / heat)
     bool external_heat = false;
     bool fp8 = false;            // e4m3 twin (1 byte per element) of a bf16 tensor, input of an fp8 convolution
+    bool split = false;          // bf16x3 engine: split twin ([16 hi | 16 lo] bf16 per 16-channel group = 4 bytes per element) of an fp32 tensor
     int twin = -1;               // index of this tensor's fp8 twin, if any
     float scale = 0.f;           // calibrated per-tensor scale of the twin: amax / 448
     int first = -1, last = -1;   // producing / last consuming op
@@ -119,6 +122,7 @@ struct sncal_hrnet {
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
     bool fp8 = false, fp8_calibrated = false, calibrating = false;
+    bool x3 = false;                          // SNCAL_BF16X3: the fp32 engine with split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4
     unsigned fp8_stages = 0;                  // bit s: stage s selected (0 = all stages)
     std::vector<int> fp8_widths;              // selected channel widths (empty = all)
     unsigned* d_amax = nullptr;               // calibration: per-tensor max |x| (float bit patterns)
@@ -453,6 +457,16 @@ struct Builder {
         { Op op; op.type = OP_DECODE; op.in = net.t_heat; net.ops.push_back(op); }
         // C5: every wide 3x3 stride-1 convolution may run in fp8 -> its input tensor gets an e4m3 twin (allocated only while
         // the layer is selected, see layout())
+        if (net.x3)
+            for (const Op& op : net.ops) {
+                if (op.type != OP_CONV || op.group != GRP_ALL) continue;
+                const ConvLayer& L = net.layers[op.conv];
+                if (L.k == 3 && L.stride == 1 && L.stage >= 2 && L.cin % 16 == 0 && L.cout % 16 == 0 && net.tensors[op.in].C == L.cin && net.tensors[op.in].twin < 0) {
+                    const int tw = new_tensor(L.cin);
+                    net.tensors[tw].split = true;
+                    net.tensors[op.in].twin = tw;
+                }
+            }
         if (net.fp8)
             for (const Op& op : net.ops) {
                 if (op.type != OP_CONV) continue;
@@ -560,6 +574,42 @@ int pack_layer(sncal_hrnet& net, ConvLayer& L) {
 bool tt_shape_ok(const sncal_hrnet& net, const ConvLayer& L) {
     return net.dtype == SNCAL_BF16 && L.k == 3 && L.stride == 1 && L.cin == L.cin_phys && L.cin % TT_CIN == 0 &&
            L.cout % TT_COUT == 0 && L.cout <= 480;
+}
+
+// bf16x3 engine: [nb][16-channel chunk c][tap 9][part: hi, lo][32-row block 3][lane 64] x 8 bf16 -- the two-team kernel's stage layout
+// with the stage's two K = 16 steps holding the hi and the lo parts of the SAME 16 input channels: lane l holds output channel
+// nb * 96 + mb * 32 + (l & 31) (zero rows above the layer's width: a 48-channel layer runs as one padded 96-channel block), input
+// channels c * 16 + (l >> 5) * 8 + 0..7 of the tap; hi = bf16(w), lo = bf16(w - hi), w = folded weight in fp32.
+bool x3_shape_ok(const sncal_hrnet& net, const ConvLayer& L) {
+    return net.x3 && net.dtype == SNCAL_F32 && L.k == 3 && L.stride == 1 && L.stage >= 2 && L.cin == L.cin_phys && L.cin % 16 == 0 &&
+           L.cout % 16 == 0 && L.cout <= 480;
+}
+inline float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
+    if (L.d_w_x3) { (void)hipFree(L.d_w_x3); L.d_w_x3 = nullptr; }
+    if (!x3_shape_ok(net, L)) return SNCAL_OK;
+    const int chunks = L.cin / 16, nblk = (L.cout + TT_COUT - 1) / TT_COUT;
+    std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 2 * 3 * 64 * 8, 0);
+    for (int nb = 0; nb < nblk; ++nb)
+        for (int c = 0; c < chunks; ++c)
+            for (int s = 0; s < 9; ++s)
+                for (int mb = 0; mb < 3; ++mb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = nb * TT_COUT + mb * 32 + (lane & 31);
+                        if (co >= L.cout) continue;
+                        uint16_t* hi = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 0) * 3 + mb) * 64 + lane) * 8;
+                        uint16_t* lo = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 1) * 3 + mb) * 64 + lane) * 8;
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = c * 16 + (lane >> 5) * 8 + e;
+                            const float w = L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co];
+                            hi[e] = f2bf(w);
+                            lo[e] = f2bf(w - bf2f(hi[e]));
+                        }
+                    }
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w_x3, host.size() * 2));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w_x3, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    return SNCAL_OK;
 }
 
 int pack_layer_tt(sncal_hrnet& net, ConvLayer& L) {
@@ -765,10 +815,11 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
     // C5: which layers run in fp8 = selected by sncal_hrnet_set_fp8_layers AND served by the two-team kernel at this size (the only
     // kernel that reads an e4m3 twin): twins, producers' outputs and the dispatch below all key on this ONE predicate, so a selected
     // layer that falls back to the generic kernel (SNCAL_CONV_TT=0, an odd channel offset, a size limit) simply stays bf16
-    for (ConvLayer& L : net.layers) L.fp8_on = false;
+    for (ConvLayer& L : net.layers) { L.fp8_on = false; L.x3_on = false; }
     for (const Op& op : net.ops) {
         if (op.type != OP_CONV || !op_active(net, op)) continue;
         ConvLayer& L = net.layers[op.conv];
+        L.x3_on = net.x3 && L.d_w_x3 != nullptr && T[op.in].twin >= 0 && tt_eligible(net, op, sb);
         bool w_ok = net.fp8_widths.empty();
         for (int w : net.fp8_widths) w_ok = w_ok || w == L.cout;
         const bool s_ok = net.fp8_stages == 0 || ((net.fp8_stages >> L.stage) & 1u);
@@ -814,7 +865,7 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
             for (int k = 0; k < op.head_nsrc; ++k) bf(op.head_src[k]);
             for (int k = 0; k < op.head_nfold; ++k) bf(op.head_fold[k]);
             if (op.in >= 0) {
-                const bool f8 = op.type == OP_CONV && net.layers[op.conv].fp8_on && T[op.in].twin >= 0;
+                const bool f8 = op.type == OP_CONV && (net.layers[op.conv].fp8_on || net.layers[op.conv].x3_on) && T[op.in].twin >= 0;
                 if (f8) twin_used[op.in] = 1; else bf(op.in);
             }
         }
@@ -963,10 +1014,16 @@ void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVarian
 
 // ---- two-team persistent kernel for the wide 3x3 stride-1 convolutions (conv_tt.hip) --------------------------------
 bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb) {
-    if (!net.use_conv_tt || net.dtype != SNCAL_BF16 || op.type != OP_CONV || op.out_f32) return false;
+    if (!net.use_conv_tt || op.type != OP_CONV) return false;
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
+    if (net.x3) {                                   // bf16x3 engine: fp32 tensors, split twin in, fp32 out
+        if (net.dtype != SNCAL_F32 || !L.d_w_x3 || ti.C != L.cin || ti.twin < 0 || to.C % 8 || op.out_coff % 8) return false;
+        const size_t in_bytes = (size_t)sb * ti.H * ti.W * ti.C * 4, out_bytes = (size_t)sb * to.H * to.W * to.C * 4;
+        return in_bytes < (1u << 31) && out_bytes < (1ull << 32) && (size_t)((L.cout + TT_COUT - 1) / TT_COUT) * (L.cin / 16) * 9 * 6 * 1024 < (1u << 31);
+    }
+    if (net.dtype != SNCAL_BF16 || op.out_f32) return false;
     if (!L.d_w_tt || ti.C != L.cin) return false;                                   // packed at finalize for the eligible shapes
     if (to.C % 8 || op.out_coff % 8) return false;
     const size_t in_bytes = (size_t)sb * ti.H * ti.W * ti.C * 2, out_elems = (size_t)sb * to.H * to.W * to.C;
@@ -995,6 +1052,14 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
     m.w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * m.chunks * 9 * 6 * 1024);
     m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C * 2);
     m.hp1_magic = 0xFFFFFFFFu / (unsigned)(ti.H + 1) + 1u;
+    if (L.x3_on) {           // bf16x3: split twin in (a bf16 tensor of 2 C pseudo-channels), 16-channel stages, hi / lo weights, fp32 out
+        m.in = ws + net.tensors[ti.twin].offset;
+        m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C * 4);
+        m.Cin = 2 * L.cin;
+        m.chunks = L.cin / 16;
+        m.w = L.d_w_x3;
+        m.w_bytes = (unsigned)((size_t)((L.cout + TT_COUT - 1) / TT_COUT) * m.chunks * 9 * 6 * 1024);
+    }
     if (L.fp8_on) {          // C5: e4m3 twin in, 64-channel stages, e4m3 weights; outputs: bf16 if anybody reads it, twin if an fp8 conv follows
         m.in = ws + net.tensors[ti.twin].offset;
         m.in_bytes = (unsigned)((size_t)sb * ti.H * ti.W * ti.C);
@@ -1032,7 +1097,7 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int oi = 0; oi < n; ++oi) {
         const TTMember& m = mem[order[oi]];
-        const int tiles_y = (m.N * (m.H + 1) + TT_TH - 1) / TT_TH, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = m.cout / TT_COUT;
+        const int tiles_y = (m.N * (m.H + 1) + TT_TH - 1) / TT_TH, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = (m.cout + TT_COUT - 1) / TT_COUT;
         const long total = (long)tiles_y * tiles_x * nblk;
         for (long i = 0; i < total; ++i) {
             const int x = (int)(i * 8 / total);
@@ -1073,13 +1138,18 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
 int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* ws, hipStream_t stream) {
     TTParams tp;
     memset(&tp, 0, sizeof(tp));
-    const bool fp8 = net.layers[ops[0].conv].fp8_on;
+    const bool fp8 = net.layers[ops[0].conv].fp8_on, x3 = net.layers[ops[0].conv].x3_on;
     const sncal::LaunchEvents armed = sncal::launch_events();        // the profiling event pair belongs to the convolution launch,
     sncal::launch_events() = sncal::LaunchEvents{};                  // not to the calibration / quantisation helpers in front of it
     for (int i = 0; i < n; ++i) {
         if (net.calibrating && net.tensors[ops[i].in].twin >= 0) {        // C5 calibration: max |x| of every candidate input tensor
             const Tensor& ti = net.tensors[ops[i].in];
             const int rc = launch_absmax_bf16(ws + ti.offset, (size_t)sb * ti.H * ti.W * ti.C, net.d_amax + ops[i].in, stream);
+            if (rc) return rc;
+        }
+        if (x3) {                                                        // bf16x3: the fp32 input's split twin (hi | lo planes)
+            const Tensor& ti = net.tensors[ops[i].in];
+            const int rc = launch_split_f32(ws + ti.offset, ws + net.tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream);
             if (rc) return rc;
         }
         if (fp8 && !twin_written_by_producer(net, ops[i].in, sb)) {      // first fp8 conv of a chain: quantise its input here
@@ -1105,7 +1175,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
     if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
-    launch_conv_tt(tp, it->second.n_wgs, fp8, stream);
+    launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -1137,7 +1207,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
     }
     return SNCAL_OK;
 }
@@ -1180,7 +1250,7 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         int couts = 0;
         for (int i = 0; i < n; ++i) {
             all_tt = all_tt && tt_eligible(net, ops[i], sb) && net.layers[ops[i].conv].fp8_on == net.layers[ops[0].conv].fp8_on;
-            couts += net.layers[ops[i].conv].cout;
+            couts += (net.layers[ops[i].conv].cout + TT_COUT - 1) / TT_COUT * TT_COUT;
         }
         static const bool fp8_singles = getenv("SNCAL_FP8_SINGLES") != nullptr;          // debugging aid
         bool any_fp8 = false;
@@ -1232,7 +1302,7 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
 
 extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal_hrnet** out) {
     SNCAL_CHECK_ARG(desc && out, "sncal_hrnet_create: null pointer");
-    SNCAL_CHECK_ARG(dtype == SNCAL_F32 || dtype == SNCAL_BF16 || dtype == SNCAL_FP8, "sncal_hrnet_create: dtype %d", dtype);
+    SNCAL_CHECK_ARG(dtype == SNCAL_F32 || dtype == SNCAL_BF16 || dtype == SNCAL_FP8 || dtype == SNCAL_BF16X3, "sncal_hrnet_create: dtype %d", dtype);
     SNCAL_CHECK_ARG(desc->stem_width == 64, "stem_width must be 64 (layer1 input is hard-coded, hrnet.py:273)");
     SNCAL_CHECK_ARG(desc->num_classes >= 2 && desc->num_classes <= 64, "num_classes %d out of range", desc->num_classes);
     SNCAL_CHECK_ARG(desc->upscale == 1 || desc->upscale == 2, "upscale must be 1 or 2");
@@ -1248,6 +1318,8 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
     net->desc = *desc;
     net->fp8 = dtype == SNCAL_FP8;            // C5: the bf16 engine with e4m3 arithmetic in the wide 3x3 stride-1 convolutions
     if (net->fp8) dtype = SNCAL_BF16;
+    net->x3 = dtype == SNCAL_BF16X3;          // the fp32 engine with split-bf16 3x3 convolutions
+    if (net->x3) dtype = SNCAL_F32;
     net->dtype = dtype;
     net->ge = dtype == SNCAL_BF16 ? 8 : 4;
     net->esize = dtype == SNCAL_BF16 ? 2 : 4;
@@ -1263,7 +1335,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_oscale) (void)hipFree(L.d_oscale); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
@@ -1331,6 +1403,8 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         rc = pack_layer_tt(*net, L);
         if (rc) return rc;
         rc = pack_layer_fp8(*net, L);
+        if (rc) return rc;
+        rc = pack_layer_x3(*net, L);
         if (rc) return rc;
         std::vector<float>().swap(L.w);
     }
@@ -1484,7 +1558,7 @@ extern "C" int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_o
         const ConvLayer& L = net->layers[op.conv];
         snprintf(out->name, sizeof(out->name), "%s", L.name.c_str());
         out->cin = L.cin; out->cout = L.cout; out->ksize = L.k; out->stride = L.stride; out->col_off = L.col_off;
-        out->fp8 = L.fp8_on ? 1 : 0;
+        out->fp8 = L.fp8_on ? 1 : L.x3_on ? 2 : 0;
     }
     if (idx < (int)net->op_label.size()) snprintf(out->kernel, sizeof(out->kernel), "%s", net->op_label[idx].c_str());
     return SNCAL_OK;

@@ -38,5 +38,7 @@ int launch_logsoftmax_decode(const float* logits, int cstride, int C, int B, int
 // bf16 -> fp8 e4m3 quantisation x / scale saturated to +-448
 int launch_absmax_bf16(const void* x, size_t n, unsigned* d_out, hipStream_t s);
 int launch_quantize_fp8(const void* x, void* y, size_t n, float scale, hipStream_t s);
+// fp32 -> split twin ([16 hi | 16 lo] bf16 per 16-channel group) for the bf16x3 convolutions; n % 16 == 0 (C % 16 == 0)
+int launch_split_f32(const void* x, void* y, size_t n, hipStream_t s);
 
 }  // namespace sncal

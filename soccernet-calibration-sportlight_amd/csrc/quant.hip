@@ -47,6 +47,30 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16x8* __restr
     }
 }
 
+// fp32 [N][H][W][C] -> split twin for the bf16x3 convolutions (conv_tt.hip MODE 2): per pixel and 16-channel group [16 hi | 16 lo] bf16
+// with hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-17 relative).  One thread = 8 channels: 32 B read, 16 B + 16 B written.
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, bf16x8* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 a = x[2 * i], b = x[2 * i + 1];
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { h[e] = (__bf16)f[e]; l[e] = (__bf16)(f[e] - (float)h[e]); }
+        const size_t g16 = i >> 1, half = i & 1;            // 16-channel group, which 8 of its channels
+        y[g16 * 4 + half] = h;
+        y[g16 * 4 + 2 + half] = l;
+    }
+}
+
+int launch_split_f32(const void* x, void* y, size_t n, hipStream_t s) {
+    if (n % 16) { set_error("split: element count %zu is not a multiple of 16", n); return SNCAL_ERR_ARG; }
+    const size_t n8 = n / 8;
+    const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 4096);
+    SNCAL_LAUNCH(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<bf16x8*>(y), n8);
+    SNCAL_CHECK_LAUNCH();
+    return SNCAL_OK;
+}
+
 int launch_absmax_bf16(const void* x, size_t n, unsigned* d_out, hipStream_t s) {
     if (n % 8) { set_error("absmax: element count %zu is not a multiple of 8", n); return SNCAL_ERR_ARG; }
     const size_t n8 = n / 8;

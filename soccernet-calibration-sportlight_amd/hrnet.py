@@ -19,7 +19,7 @@ from . import _lib
 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs')
 BN_EPS = 1e-5
-DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2, 'e4m3': 2}
+DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2, 'e4m3': 2, 'bf16x3': 3, 'x3': 3}
 
 
 def _plain(obj):
@@ -255,7 +255,7 @@ class HRNetHeatmap:
                             **{'in': po.in_}, res=po.res, out=po.out, base=po.base, src=list(po.src)[:po.nsrc],
                             head_direct=po.head_direct, head_src=list(po.head_src)[:po.head_nsrc],
                             head_fold=list(po.head_fold)[:po.head_nfold], relu=bool(po.relu), out_coff=po.out_coff,
-                            out_f32=bool(po.out_f32), fp8=bool(po.fp8), kernel=po.kernel.decode()))
+                            out_f32=bool(po.out_f32), fp8=po.fp8 == 1, x3=po.fp8 == 2, kernel=po.kernel.decode()))
         return out
 
     def plan_tensor(self, tid):

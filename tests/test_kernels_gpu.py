@@ -192,7 +192,7 @@ def run_case(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, want_heat=True):
 def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
     ops, taps, net = run_case(sncal, cuda, cfg, sd, x, dtype, fp8_layers)
     W = Weights(net, sd, cuda)
-    f32_engine = dtype == 'fp32'
+    f32_engine = dtype in ('fp32', 'bf16x3')
     act_round = (lambda t: t) if f32_engine else bf16r
     rel_out = 1e-5 if f32_engine else BF16_ULP
     abs_out = 2e-4 if f32_engine else 1e-3
@@ -249,17 +249,23 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 # lose up to 2^-13 of its group's maximum: <= 7 x 2^-14 of the sum of |x w| on average, one-sided.  Measured on these
                 # layers: up to 1.5e-4 = 2^-12.7 of sum |x w|; allowed: 2^-11 of it (a wrong tap moves the sum by ~2^-6 of it)
                 fp8_slack = 2.0 ** -11 * conv_ref(xin.abs(), wq.abs(), 1) * oscale[None, :, None, None]
+            elif op.get('x3'):
+                # bf16x3: fp32 operands split into bf16 hi + lo, hi.hi + hi.lo + lo.hi in fp32: every product is good to ~2^-16 of
+                # itself, so the sum is good to a few 1e-5 of sum |x w| (measured below 1e-5); a wrong tap is 2^-6 of it
+                xin = nchw(T(op, op['in']))[:, :op['cin']]
+                y = conv_ref(xin, w, op['stride']) + shift[None, :, None, None]
+                fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride'])
             else:
                 xin = nchw(T(op, op['in']))[:, :op['cin']]
                 y = conv_ref(xin, act_round(w), op['stride']) + shift[None, :, None, None]
-            if not op['fp8']:
+            if not op['fp8'] and not op.get('x3'):
                 fp8_slack = 0.0
             if op['res'] >= 0:
                 y = y + nchw(T(op, op['res']))[:, op['out_coff']:op['out_coff'] + op['cout']]
             if op['relu']:
                 y = torch.relu(y)
             to = net.plan_tensor(op['out'])
-            kern = label if not op['fp8'] else 'conv_tt<fp8,k3,s1,8x32x96>'
+            kern = 'conv_tt<fp8,k3,s1,8x32x96>' if op['fp8'] else 'conv_tt<bf16x3,k3,s1,8x32x96>' if op.get('x3') else label
             name = f"{op['name']} {to['H']}x{to['W']} {op['cin']}->{op['cout']}" + ('+res' if op['res'] >= 0 else '')
             checked = False
             if to['alive'] and not (op['fp8'] and not _bf16_written(net, ops, op)):
@@ -445,3 +451,13 @@ def test_every_launch_of_the_fp32_engine_w18(sncal, cuda):
     stats = verify_plan(sncal, cuda, 'hrnet_w18', sd, _frames(3, 135, 240, 17, cuda), 'fp32', tag='w18 135x240 fp32')
     _report(stats, 'fp32_w18_135x240')
     assert any(k.startswith('conv<f32') for k in stats)
+
+
+def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
+    """The fp32-class engine: fp32 tensors everywhere, the 3x3 stride-1 convolutions of stages 2-4 (wide branches and the 48-channel
+    branch, run as a padded 96-channel block) on the two-team kernel in split-bf16 arithmetic -- each against torch fp32 on the
+    fp32 operands it was given (the split twin the kernel actually reads is a pure function of them)."""
+    sd = _weights('hrnet_w48')
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'bf16x3', tag='w48 540p bf16x3')
+    _report(stats, 'bf16x3_w48_540p')
+    assert stats['conv_tt<bf16x3,k3,s1,8x32x96>']['ops'] == 144 + 64

@@ -216,6 +216,11 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
         const unsigned out_bytes = (unsigned)(M.N * M.H * M.W * M.out_cstride * 4);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.res ? M.res : M.in), 0, M.res ? (int)out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(M.out ? M.out : const_cast<void*>(M.in), 0, M.out ? (int)out_bytes : 0, 0x00020000);
+        // split twin of the output for the next bf16x3 convolution ([16 hi | 16 lo] bf16 per 16-channel group: 4 bytes per element like
+        // the fp32 tensor; written here the consumer needs no separate split pass).  Twin tensors are dense: stride = the layer's width.
+        const unsigned twin_bytes = (unsigned)(M.N * M.H * M.W * M.cout * 4);
+        const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(M.out8 ? M.out8 : const_cast<void*>(M.in), 0, M.out8 ? (int)twin_bytes : 0, 0x00020000);
+        const bool has_twin = M.out8 != nullptr;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const bool has_res = M.res != nullptr;
         estamp();
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
             const int y = srow - (int)f * (M.H + 1);
             const bool row_ok = ((int)f < M.N) & (y < M.H);
             const unsigned soff = row_ok ? (unsigned)(((((int)f * M.H + y) * M.W + col0) * M.out_cstride + M.out_coff + nb * TT_COUT) * 4) : 0u;
+            const unsigned soff_tw = row_ok ? (unsigned)(((((int)f * M.H + y) * M.W + col0) * M.cout + nb * TT_COUT) * 4) : 0u;
             if (jr == 1) estamp();
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
@@ -267,6 +273,17 @@ __global__ __launch_bounds__(512, 2) void conv_tt_kernel(const TTParams P) {
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, voff, soff, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, voff, soff + 16u, 0);
                 asm volatile("s_nop 3" :: "v"(o0), "v"(o1) : "memory");
+                if (has_twin) {                  // wave-uniform: hi = bf16(y), lo = bf16(y - hi), 16 bytes each, lo 32 bytes behind hi
+                    bf16x8 th, tl;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { th[k] = (__bf16)v[k]; tl[k] = (__bf16)(v[k] - (float)th[k]); }
+                    u32x4 t0 = __builtin_bit_cast(u32x4, th), t1 = __builtin_bit_cast(u32x4, tl);
+                    const unsigned voff_tw = ok ? (unsigned)(px * M.cout * 4 + (grp >> 1) * 64 + (grp & 1) * 16) : 0x80000000u;
+                    asm volatile("" : "+v"(t0), "+v"(t1));
+                    __builtin_amdgcn_raw_buffer_store_b128(t0, rs_tw, voff_tw, soff_tw, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(t1, rs_tw, voff_tw, soff_tw + 32u, 0);
+                    asm volatile("s_nop 3" :: "v"(t0), "v"(t1) : "memory");
+                }
             }
         }
         estamp();

@@ -1037,6 +1037,10 @@ bool twin_written_by_producer(const sncal_hrnet& net, int t, int sb) {
     const int pi = t >= 0 && t < (int)net.producer.size() ? net.producer[t] : -1;
     if (pi < 0) return false;
     const Op& po = net.ops[pi];
+    if (po.type == OP_CONV && net.layers[po.conv].x3_on && tt_eligible(net, po, sb)) {        // bf16x3: the producer's epilogue writes the split twin
+        static const bool x3_split_always = getenv("SNCAL_X3_NO_TWIN_OUT") != nullptr;            // (dense outputs only)
+        return !x3_split_always && po.out_coff == 0 && net.tensors[po.out].C == net.layers[po.conv].cout;
+    }
     return po.type == OP_CONV && net.layers[po.conv].fp8_on && tt_eligible(net, po, sb);
 }
 
@@ -1059,6 +1063,10 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
         m.chunks = L.cin / 16;
         m.w = L.d_w_x3;
         m.w_bytes = (unsigned)((size_t)((L.cout + TT_COUT - 1) / TT_COUT) * m.chunks * 9 * 6 * 1024);
+        // outputs: the split twin when a bf16x3 convolution reads this tensor next, the fp32 tensor when anybody else does
+        const bool twin_out = to.twin >= 0 && net.tensors[to.twin].first >= 0 && twin_written_by_producer(net, op.out, sb);
+        m.out8 = twin_out ? ws + net.tensors[to.twin].offset : nullptr;
+        if (twin_out && !net.need_bf16[op.out]) m.out = nullptr;
     }
     if (L.fp8_on) {          // C5: e4m3 twin in, 64-channel stages, e4m3 weights; outputs: bf16 if anybody reads it, twin if an fp8 conv follows
         m.in = ws + net.tensors[ti.twin].offset;
@@ -1147,7 +1155,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
             const int rc = launch_absmax_bf16(ws + ti.offset, (size_t)sb * ti.H * ti.W * ti.C, net.d_amax + ops[i].in, stream);
             if (rc) return rc;
         }
-        if (x3) {                                                        // bf16x3: the fp32 input's split twin (hi | lo planes)
+        if (x3 && !twin_written_by_producer(net, ops[i].in, sb)) {       // bf16x3: the fp32 input's split twin, unless its producer wrote it
             const Tensor& ti = net.tensors[ops[i].in];
             const int rc = launch_split_f32(ws + ti.offset, ws + net.tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream);
             if (rc) return rc;

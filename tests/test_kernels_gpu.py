@@ -252,7 +252,9 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             elif op.get('x3'):
                 # bf16x3: fp32 operands split into bf16 hi + lo, hi.hi + hi.lo + lo.hi in fp32: every product is good to ~2^-16 of
                 # itself, so the sum is good to a few 1e-5 of sum |x w| (measured below 1e-5); a wrong tap is 2^-6 of it
-                xin = nchw(T(op, op['in']))[:, :op['cin']]
+                raw = T(op, ti['twin'])                       # the operand the kernel reads: the split twin, hi + lo = x to 2^-17
+                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                xin = (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2).contiguous()
                 y = conv_ref(xin, w, op['stride']) + shift[None, :, None, None]
                 fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride'])
             else:
@@ -268,12 +270,19 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             kern = 'conv_tt<fp8,k3,s1,8x32x96>' if op['fp8'] else 'conv_tt<bf16x3,k3,s1,8x32x96>' if op.get('x3') else label
             name = f"{op['name']} {to['H']}x{to['W']} {op['cin']}->{op['cout']}" + ('+res' if op['res'] >= 0 else '')
             checked = False
-            if to['alive'] and not (op['fp8'] and not _bf16_written(net, ops, op)):
+            if to['alive'] and not ((op['fp8'] or op.get('x3')) and not _bf16_written(net, ops, op)):
                 got = nchw(T(op, op['out']))[:, op['out_coff']:op['out_coff'] + op['cout']]
                 if op['out_f32']:
                     check(name, got, y, 1e-5 if f32_engine else 2.0 ** -9, abs_out, stats, kern)     # fp32 logits of bf16 operands
                 else:
                     check(name, got, y, rel_out, abs_out + fp8_slack, stats, kern)
+                checked = True
+            if op.get('x3') and to['twin'] >= 0 and net.plan_tensor(to['twin'])['alive'] and (op['idx'], to['twin']) in taps:
+                # split twin written by the epilogue: [16 hi | 16 lo] bf16 per 16-channel group; hi + lo reproduces y to 2^-17
+                raw = T(op, to['twin'])                                                  # fp32-typed storage, (N,H,W,C)
+                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                got_t = (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
+                check(name + ' [split twin out]', got_t, y, 1e-5 + 2.0 ** -16, abs_out + fp8_slack, stats, kern + ' split out')
                 checked = True
             if op['fp8'] and to['twin'] >= 0 and net.plan_tensor(to['twin'])['alive']:
                 tw_o = net.plan_tensor(to['twin'])
@@ -321,7 +330,7 @@ def _bf16_written(net, ops, op):
         readers = [o['res'], o['base'], o['head_direct']] + o['src'] + o['head_src'] + o['head_fold']
         if t in readers:
             return True
-        if o['in'] == t and not (o['type'] == 'conv' and o['fp8']):
+        if o['in'] == t and not (o['type'] == 'conv' and (o['fp8'] or o.get('x3'))):
             return True
     return False
 
@@ -456,8 +465,10 @@ def test_every_launch_of_the_fp32_engine_w18(sncal, cuda):
 def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
     """The fp32-class engine: fp32 tensors everywhere, the 3x3 stride-1 convolutions of stages 2-4 (wide branches and the 48-channel
     branch, run as a padded 96-channel block) on the two-team kernel in split-bf16 arithmetic -- each against torch fp32 on the
-    fp32 operands it was given (the split twin the kernel actually reads is a pure function of them)."""
+    split twin it reads (hi + lo; written by the producing convolution's epilogue or by split_f32_kernel), its fp32 output and the
+    split twin it hands on."""
     sd = _weights('hrnet_w48')
     stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'bf16x3', tag='w48 540p bf16x3')
     _report(stats, 'bf16x3_w48_540p')
-    assert stats['conv_tt<bf16x3,k3,s1,8x32x96>']['ops'] == 144 + 64
+    k = 'conv_tt<bf16x3,k3,s1,8x32x96>'          # 144 wide + 64 48-channel convolutions, each checked on its fp32 output, its twin, or both
+    assert stats[k]['ops'] >= 100 and stats[k + ' split out']['ops'] >= 150 and stats[k]['ops'] + stats[k + ' split out']['ops'] >= 208

@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 FLOP_KEYPOINT_NET = 2 * 253910384640
 FLOP_LINE_NET = 2 * 185690000000
 FLOP_KEYPOINT_NET_1080P = 2 * 1014180000000
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0, 'bf16x3': 2500.0 / 3.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
 BATCH = 64
 SOLVER_KW = dict(conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter', lines_file=None,
                  max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0, min_points_per_plane=6,
@@ -172,69 +172,91 @@ def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0, nb=8):
             'serial_fps': round(1.0 / (t_net + t_dec + 1.0 / fps_pool), 4)}
 
 
-def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, flop_frame=None):
-    """The benchmarked engine vs this build's exact-fp32 engine on the SAME frames (outside the timed region).  Returns (parity,
-    fp32): `fp32` is the reference-precision leg of the line -- HRNetMetaModel.predict is fp32 (metamodel.py:127-134) -- measured
-    like the main leg: the same step (forward + fused decode + solve of the decoded keypoints), warm-up, one step profiled launch by
-    launch to find the dominant kernel, then `steps` timed steps with HIP events on that kernel's launches only."""
-    net32 = sncal_amd.HRNetHeatmap(cfg_name, dtype='fp32', device=dev)
-    net32.load_state_dict(sd)
-    pipe = sncal_amd.CalibrationPipeline(net32, cc, decode_size=(540, 960))
+def engine_leg(sncal_amd, cfg_name, sd, x, cc, dev, dtype, peak, what, steps=3, flop_frame=None):
+    """One more engine on the SAME frames and the SAME step (forward + fused decode + solve of the decoded keypoints), outside the
+    timed region of the main leg, measured like it: warm-up, one step profiled launch by launch to find the dominant kernel, then
+    `steps` timed steps with HIP events on that kernel's launches only.  Returns (object for the line, keypoints, camera records)."""
+    net = sncal_amd.HRNetHeatmap(cfg_name, dtype=dtype, device=dev)
+    net.load_state_dict(sd)
+    pipe = sncal_amd.CalibrationPipeline(net, cc, decode_size=(540, 960))
     out = pipe.submit(x)
     pipe.join()
     torch.cuda.synchronize()
-    net32.set_profiling(1)
+    net.set_profiling(1)
     pipe.submit(x)
     pipe.join()
     torch.cuda.synchronize()
-    warm = net32.get_profile()
-    net32.set_profiling(2)
+    warm = net.get_profile()
+    net.set_profiling(2)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = pipe.submit(x)
     pipe.join()
     torch.cuda.synchronize()
-    dt32 = time.perf_counter() - t0
-    dom = net32.get_profile()
-    net32.set_profiling(0)
-    fps32 = steps * x.shape[0] / dt32
-    fp32 = {'value': round(fps32, 2), 'unit': 'frames/s', 'ms_per_step': round(dt32 / steps * 1e3, 2), 'steps': steps, 'frames': int(x.shape[0]),
-            'dtype': 'fp32', 'what': 'the same step on the exact-fp32 MFMA engine (v_mfma_f32_16x16x4_f32): the reference\'s own arithmetic, load_model\'s default'}
+    dt = time.perf_counter() - t0
+    dom = net.get_profile()
+    net.set_profiling(0)
+    fps = steps * x.shape[0] / dt
+    obj = {'value': round(fps, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps, 'frames': int(x.shape[0]),
+           'dtype': dtype, 'what': what}
     if len(dom) == 1 and dom[0]['ms'] > 0:
         d = dom[0]
         tot = sum(p['ms'] for p in warm)
         wd = next((p for p in warm if p['kernel'] == d['kernel']), None)
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        fp32['roofline'] = {'bound': 'mfma', 'kernel': d['kernel'], 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
-                            'frac': round(ach / PEAK_TFLOPS['fp32'], 4), 'launches': d['launches'],
-                            'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2),
-                            'share_of_gpu_time': round(wd['ms'] / tot, 4) if wd and tot else None}
+        obj['roofline'] = {'bound': 'mfma', 'kernel': d['kernel'], 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': round(ach / peak, 4), 'launches': d['launches'],
+                           'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2),
+                           'share_of_gpu_time': round(wd['ms'] / tot, 4) if wd and tot else None}
         if flop_frame:
-            fp32['network_tflops_reference_formulation'] = round(fps32 * flop_frame / 1e12, 1)
-            fp32['network_frac_of_fp32_mfma_peak'] = round(fps32 * flop_frame / 1e12 / PEAK_TFLOPS['fp32'], 4)
-    kp32 = out[0].cpu().numpy()
-    kpf = kp_fast.cpu().numpy()
+            obj['network_tflops_reference_formulation'] = round(fps * flop_frame / 1e12, 1)
+            obj['network_frac_of_peak'] = round(fps * flop_frame / 1e12 / peak, 4)
+    kp = out[0].cpu().numpy()
+    recs = cc.records(out[1])
+    del pipe, net
+    return obj, kp, recs
+
+
+def parity_of(kp32, r32, kpf, rf, versus):
+    """Keypoints / cameras of one engine against the exact-fp32 engine's on the same frames (all frames with two cameras)."""
     same = (kp32[..., :2] == kpf[..., :2]).all(-1)                       # (B,57) identical (x, y) indices
     usable = kp32[..., 2] >= 0.2                                         # rows any of the solver's thresholds can take
     move = np.abs(kp32[..., :2] - kpf[..., :2]).max(-1)
-    # both keypoint sets through the same solve call (no line points), so the comparison is like for like in every workload
-    r32, rf = cc.records(out[1]), cc.records(cc.solve_device(kp_fast))
     both = [i for i in range(len(r32)) if r32[i].status != 0 and rf[i].status != 0]
-    deltas = [abs(rf[i].rmse - r32[i].rmse) / r32[i].rmse for i in both if r32[i].rmse > 0]      # ALL frames with two cameras
-    parity = {'vs': 'exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py, kernel by kernel to torch fp32 by tests/test_kernels_gpu.py)',
-              'workload': 'deep path: the keypoint codes travel through every backbone tensor (synth.deep_state_dict)',
-              'frames': int(x.shape[0]),
-              'index_agreement': round(float(same[usable].mean()) if usable.any() else 1.0, 6),
-              'usable_keypoints': int(usable.sum()),
-              'moved_usable_keypoints': int((~same[usable]).sum()), 'moved_usable_max_px': float(move[usable].max()) if usable.any() else 0.0,
-              'index_agreement_all_rows': round(float(same.mean()), 6),
-              'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
-              'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_benchmarked': sum(r.status != 0 for r in rf),
-              'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
-              'rmse_rel_delta_median': float(f'{float(np.median(deltas)):.3e}') if deltas else None,
-              'frames_rmse_rel_delta_le_1e-4': int(sum(d <= 1e-4 for d in deltas)),
-              'solve_parity': 'vs the build\'s own oracle only: OpenCV parity unpinned (cv2 not installable offline)'}
-    return parity, fp32
+    deltas = [abs(rf[i].rmse - r32[i].rmse) / r32[i].rmse for i in both if r32[i].rmse > 0]
+    return {'vs': versus,
+            'workload': 'deep path: the keypoint codes travel through every backbone tensor (synth.deep_state_dict)',
+            'frames': int(kp32.shape[0]),
+            'index_agreement': round(float(same[usable].mean()) if usable.any() else 1.0, 6),
+            'usable_keypoints': int(usable.sum()),
+            'moved_usable_keypoints': int((~same[usable]).sum()), 'moved_usable_max_px': float(move[usable].max()) if usable.any() else 0.0,
+            'index_agreement_all_rows': round(float(same.mean()), 6),
+            'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
+            'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_engine': sum(r.status != 0 for r in rf),
+            'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
+            'rmse_rel_delta_median': float(f'{float(np.median(deltas)):.3e}') if deltas else None,
+            'frames_rmse_rel_delta_le_1e-4': int(sum(d <= 1e-4 for d in deltas)),
+            'solve_parity': 'vs the build\'s own oracle only: OpenCV parity unpinned (cv2 not installable offline)'}
+
+
+def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, flop_frame=None, main_dtype='bf16'):
+    """(parity of the benchmarked engine, fp32 object, bf16x3 object).  fp32 = the reference's own arithmetic (HRNetMetaModel.predict
+    is fp32, metamodel.py:127-134) on the exact-fp32 MFMA engine, load_model's default; bf16x3 = the fp32-class engine (split-bf16
+    3x3 convolutions), with its own parity against fp32."""
+    VS = ('exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py, kernel by kernel to torch fp32 by '
+          'tests/test_kernels_gpu.py)')
+    fp32, kp32, r32 = engine_leg(sncal_amd, cfg_name, sd, x, cc, dev, 'fp32', PEAK_TFLOPS['fp32'],
+                                 'the same step on the exact-fp32 MFMA engine (v_mfma_f32_16x16x4_f32): the reference\'s own arithmetic, load_model\'s default',
+                                 steps, flop_frame)
+    rf = cc.records(cc.solve_device(kp_fast))      # both keypoint sets through the same solve call (no line points): like for like in every workload
+    parity = parity_of(kp32, r32, kp_fast.cpu().numpy(), rf, VS)
+    x3 = None
+    if main_dtype != 'bf16x3':
+        x3, kp3, r3 = engine_leg(sncal_amd, cfg_name, sd, x, cc, dev, 'bf16x3', PEAK_TFLOPS['bf16'] / 3.0,
+                                 'the same step on the fp32-class engine: fp32 tensors and accumulation, the 3x3 stride-1 convolutions of stages 2-4 in split-bf16 '
+                                 'arithmetic (hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16; peak = bf16 dense peak / 3 products)', steps, flop_frame)
+        x3['parity'] = parity_of(kp32, r32, kp3, r3, VS)
+    return parity, fp32, x3
 
 
 def self_launch(args):
@@ -288,7 +310,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8', 'bf16x3'],
                     help="fp8: e4m3 arithmetic in the wide 3x3 convolutions (BASELINE config C5; calibrated on the first frames), the rest bf16")
     ap.add_argument('--size', default='540p', choices=['540p', '1080p'], help='input frames 960x540 (the metric) or 1920x1080 (config C5)')
     ap.add_argument('--fp8-layers', default='all', help="layer selection of --dtype fp8 (sncal_hrnet_set_fp8_layers)")
@@ -517,8 +539,9 @@ def main():
             for n in nets[1:] + lnets:
                 n._ws = None
             npar = B if args.size == '540p' else min(B, 16)
-            out['parity'], out['fp32'] = parity_leg(sncal_amd, cfg_name, sd, x[:npar], cc, kp_fast[:npar], rec_fast[:npar], dev,
-                                                    flop_frame=FLOP_KEYPOINT_NET if args.size == '540p' else FLOP_KEYPOINT_NET_1080P)
+            out['parity'], out['fp32'], out['bf16x3'] = parity_leg(sncal_amd, cfg_name, sd, x[:npar], cc, kp_fast[:npar], rec_fast[:npar], dev,
+                                                                   flop_frame=FLOP_KEYPOINT_NET if args.size == '540p' else FLOP_KEYPOINT_NET_1080P,
+                                                                   main_dtype=args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf, nb=8 if args.size == '540p' else 2)
         print(json.dumps(out), flush=True)

@@ -46,6 +46,24 @@ def test_keypoint_net_fp32_matches_reference(sncal, cuda, gold_dir, name, cfgn):
     assert np.array_equal(kp, od.keypoint_decode(heat, (540, 960)))       # fused decode == oracle decode
 
 
+def test_keypoint_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
+    """The fp32-class engine (split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4, fp32 everywhere else) against the
+    SAME reference capture as the exact-fp32 engine: bit-identical indices, confidences to 1e-5, log-probabilities (down to -52) to
+    5e-4.  Measured on this golden: exact-fp32 engine 4.6e-5 max / 8.7e-6 mean, bf16x3 2.2e-4 max / 3.9e-5 mean."""
+    g, heat, kp = _run(sncal, cuda, gold_dir, 'hrnet_w48_540x960', 'hrnet_w48', 'bf16x3')
+    assert _err(g, heat) <= 5e-4
+    assert np.array_equal(kp[..., :2], g['decode'][..., :2])
+    assert np.abs(kp[..., 2] - g['decode'][..., 2]).max() <= 1e-5
+    assert np.array_equal(kp, od.keypoint_decode(heat, (540, 960)))
+
+
+def test_line_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
+    g, heat, _ = _run(sncal, cuda, gold_dir, 'line_w48_540x960', 'line_hrnet_w48', 'bf16x3', line=True)
+    assert _err(g, heat) <= 2e-5
+    dec = sncal.EHMPredictionTransform(scale=4, sigma=3)(torch.from_numpy(heat).to(cuda)).cpu().numpy()
+    assert np.array_equal(dec[..., :2], g['decode'][..., :2])
+
+
 @pytest.mark.parametrize('name,cfgn', [('hrnet_w18_64x96', 'hrnet_w18'), ('hrnet_w48_540x960', 'hrnet_w48')])
 def test_keypoint_net_bf16_close_to_reference(sncal, cuda, gold_dir, name, cfgn):
     g, heat, kp = _run(sncal, cuda, gold_dir, name, cfgn, 'bf16')

@@ -118,7 +118,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
-    bool use_conv_t3 = getenv("SNCAL_CONV_T3") ? atoi(getenv("SNCAL_CONV_T3")) != 0 : true;      // bf16: three teams / 16-channel stages instead of two / 32
+    bool use_conv_t3 = getenv("SNCAL_CONV_T3") ? atoi(getenv("SNCAL_CONV_T3")) != 0 : false;      // bf16: three teams / 16-channel stages instead of two / 32
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;

@@ -20,6 +20,8 @@ struct HeadParams {
     const void* w1;                // stage-2 A fragments [NQ][M2][64 lanes] x 16 B
     const void* w0_32;             // head32.hip: stage-1 A fragments of v_mfma_f32_32x32x16 [NQ][ks16][64 lanes] x 16 B (rows in tt_row_channel order), or null
     const void* w1_32;             // head32.hip: stage-2 A fragments [NQ][ceil(LC / 32)][2][64 lanes] x 16 B (class rows in tt_row_channel order)
+    const void* w0_32_lo;          // headx3.hip (bf16x3 engine): the lo parts of the split weights, same layouts (w0_32 / w1_32 hold the hi parts)
+    const void* w1_32_lo;
     int ks16;                      // (Cd + sum Cf) / 16 when that is exact, else 0
     const float* bias1;            // [LC] bias of last_layer.3 (zero on the padding)
     int nsrc;
@@ -49,5 +51,8 @@ bool launch_head32(const HeadParams& p, hipStream_t s);      // head32.hip; fals
 bool head32_applies(const HeadParams& p);                  // the same test without launching
 size_t head32_decode_scratch(int B, int C, int h, int w);   // bytes of dec_row + dec_col
 void head32_decode_parts(int h, int w, int* row_parts, int* col_parts);
+// headx3.hip: the same head in split-bf16 arithmetic on fp32 tensors (bf16x3 engine); direct / fold / src are fp32 there
+bool launch_headx3(const HeadParams& p, hipStream_t s);
+bool headx3_applies(const HeadParams& p);
 
 }  // namespace sncal

@@ -1,0 +1,325 @@
+// Fused HRNet head of the bf16x3 engine: head32.hip's structure in SPLIT-bf16 arithmetic on fp32 tensors (keypoint network: stem
+// features direct, two narrow branches folded into stage 1's K, two wide branches gathered; /root/reference/src/models/hrnet/hrnet.py
+// :489-510, :316-329).
+//
+//     stage 1  MFMA x3  h = W0_d . [direct | up(narrow branches)]                    (K1 = 64 + 48 + 96 = 208 = 13 K-steps of 16)
+//     gather   MFMA x3  h += sum_s t_s . wint_s     t_s = box pixels of the wide branch's fp32 product at native resolution
+//              VALU     h = relu(h)                 (the folded-BN shift is stage 1's initial value), fp32
+//     stage 2  MFMA x3  logits += W1[:, 32-slice] . h
+// Every product a.b of two fp32 operands is a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_bf16 with hi = bf16(x),
+// lo = bf16(x - hi) (2^-17 per operand), accumulated in fp32: the arithmetic of conv_tt's MODE 2.  The weights arrive
+// split from the host (hi and lo A fragments side by side in the slice), activations are split in registers: the direct tensor and the
+// bilinear blends of the folded branches once per tile (26 B fragments), the gathered box pixels and the hidden vector per slice.
+// Why: in the fp32-class engines the head was three passes over fp32 tensors of 784 channels x 270 x 480 x 64 frames = 26 GB each
+// (per-source products 19 ms, bilinear sum 33 ms, last conv ~8 ms per 64 frames); fused, the hidden vector never leaves registers.
+// Tiling, row order (h32_row_channel), the register repack between the GEMMs and the decode-fused epilogue (per-pixel log-softmax, row
+// and column maxima of the tile) are head32.hip's; a workgroup holds 51 KB of LDS (three per CU).
+#include "common.hpp"
+#include "head.hpp"
+#include "softmax_px.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace sncal {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+constexpr int KS = 13, RB = 2;
+constexpr int X_SRC = 16 * 1024;                    // 4 waves x 2 sources x 2 KB (16 box pixels x 32 channels fp32)
+constexpr int OFF_W0H = X_SRC, OFF_W0L = OFF_W0H + KS * 1024, OFF_W1H = OFF_W0L + KS * 1024, OFF_W1L = OFF_W1H + RB * 2 * 1024;
+constexpr int OFF_B0 = OFF_W1L + RB * 2 * 1024, X_LDS = OFF_B0 + 1024;      // 52224 B
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+}
+__device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+}  // namespace
+
+template <int DEC>
+__global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile = blockIdx.x;
+    const unsigned q1 = p.tiles_x == 1 ? (unsigned)tile : __umulhi((unsigned)tile, p.tiles_x_magic);
+    const int tx = tile - (int)q1 * p.tiles_x;
+    const unsigned q2 = p.tiles_y == 1 ? q1 : __umulhi(q1, p.tiles_y_magic);
+    const int ty = (int)q1 - (int)q2 * p.tiles_y;
+    const int n = (int)q2;
+    const int oy0 = ty * 4, ox0 = tx * 32;
+    const int y = oy0 + wave, yc = min(y, p.H - 1);
+    const int x = ox0 + l31, xc = min(x, p.W - 1);
+    const bool valid = y < p.H && x < p.W;
+    const long pix = ((long)n * p.H + yc) * p.W + xc;
+
+    // ---- this wave's source boxes (its row, its 32 columns): two DMA pieces of 64 x 16 B per source and slice (a box pixel's slice is
+    // 32 fp32 = 8 lanes) and the bilinear weights of this lane's pixel over the box as a split B fragment
+    unsigned dma_voff[2][2];
+    bf16x8 wih[2], wil[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int xlast = min(ox0 + 31, p.W - 1);
+        const float fy = p.sy[s] * (float)yc;
+        int by0 = (int)fy;
+        by0 = by0 > p.Hs[s] - 1 ? p.Hs[s] - 1 : by0;
+        const int nrows = by0 < p.Hs[s] - 1 ? 2 : 1;
+        const int bx0 = (int)(p.sx[s] * (float)ox0);
+        const int bx1 = min((int)(p.sx[s] * (float)xlast) + 1, p.Ws[s] - 1);
+        const int bw = bx1 - bx0 + 1, npx = nrows * bw;            // <= 16: checked on the host for the worst case
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int slot = j * 64 + lane, pi = slot >> 3, part = slot & 7;
+            const int ly = pi >= bw ? 1 : 0, lx = pi - ly * bw;
+            dma_voff[s][j] = pi < npx ? (unsigned)((((by0 + ly) * p.Ws[s] + bx0 + lx) * p.HP) * 4 + part * 16) : 0x80000000u;
+        }
+        const float fx = p.sx[s] * (float)xc;
+        int ix = (int)fx;
+        ix = ix > p.Ws[s] - 1 ? p.Ws[s] - 1 : ix;
+        const float ly1 = fy - (float)by0, lx1 = fx - (float)ix;
+        const float w00 = (1.f - lx1) * (1.f - ly1), w01 = lx1 * (1.f - ly1), w10 = (1.f - lx1) * ly1, w11 = lx1 * ly1;
+        const int t00 = ix - bx0, t01 = t00 + (ix < p.Ws[s] - 1 ? 1 : 0), t10 = t00 + (nrows == 2 ? bw : 0), t11 = t10 + (ix < p.Ws[s] - 1 ? 1 : 0);
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = 8 * hi + e;
+            float w = 0.f;
+            w += slot == t00 ? w00 : 0.f;
+            w += slot == t01 ? w01 : 0.f;
+            w += slot == t10 ? w10 : 0.f;
+            w += slot == t11 ? w11 : 0.f;
+            wv[e] = w;
+        }
+        split8(wv, wih[s], wil[s]);
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_w0h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w0_32), 0, p.NQ * KS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0l = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w0_32_lo), 0, p.NQ * KS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w1h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1_32), 0, p.NQ * RB * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w1l = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1_32_lo), 0, p.NQ * RB * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias0), 0, p.HP * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_src[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const size_t img = (size_t)p.Hs[s] * p.Ws[s] * p.HP * 4;      // one fp32 image of source s
+        rs_src[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.src[s])) + (size_t)n * img, 0, (int)img, 0x00020000);
+    }
+    auto issue_slice = [&](int q) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src[s], (lds_void*)(smem + ((wave * 2 + s) * 2 + j) * 1024), 16, dma_voff[s][j], (unsigned)(q * 128), 0, 0);
+#pragma unroll
+        for (int i = 0; i < (KS + 3) / 4; ++i)
+            if (wave + 4 * i < KS) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0h, (lds_void*)(smem + OFF_W0H + (wave + 4 * i) * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0l, (lds_void*)(smem + OFF_W0L + (wave + 4 * i) * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024), 0, 0);
+            }
+        // RB * 2 = 4 pieces each: one per wave
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1h, (lds_void*)(smem + OFF_W1H + wave * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1l, (lds_void*)(smem + OFF_W1L + wave * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024), 0, 0);
+        if (wave == 3)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b0, (lds_void*)(smem + OFF_B0), 16, lane < 8 ? (unsigned)(lane * 16) : 0x80000000u, (unsigned)(q * 128), 0, 0);
+    };
+    issue_slice(0);
+
+    // ---- stage-1 B fragments, split: K = [direct channels | upsampled narrow branches]; lane (pixel l31, k-block hi) holds channels
+    // 16 ks + 8 hi .. + 7 of its pixel.  Segment boundaries are multiples of 8 channels.
+    bf16x8 bDh[KS], bDl[KS];
+    const float* direct = reinterpret_cast<const float*>(p.direct);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kk = ks * 16 + hi * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (kk < p.Cd) {
+            const float4 a = *reinterpret_cast<const float4*>(direct + pix * p.Cd + kk), b = *reinterpret_cast<const float4*>(direct + pix * p.Cd + kk + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            int seg0 = p.Cd;
+#pragma unroll
+            for (int f = 0; f < HEAD_MAX_FOLD; ++f) {
+                if (f < p.nfold) {
+                    if (kk >= seg0 && kk < seg0 + p.Cf[f]) {
+                        const float fy = p.fsy[f] * (float)yc, fx = p.fsx[f] * (float)xc;     // align_corners=True
+                        int iy = (int)fy, ix = (int)fx;
+                        iy = iy > p.Hf[f] - 1 ? p.Hf[f] - 1 : iy;
+                        ix = ix > p.Wf[f] - 1 ? p.Wf[f] - 1 : ix;
+                        const float ly1 = fy - (float)iy, lx1 = fx - (float)ix;
+                        const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? p.Wf[f] * p.Cf[f] : 0;
+                        const float* t = reinterpret_cast<const float*>(p.fold[f]) + (((size_t)n * p.Hf[f] + iy) * p.Wf[f] + ix) * p.Cf[f] + (kk - seg0);
+                        const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;
+                        // torch's bilinear order: rows blended in x first, then in y (upsample_add's fp32 path, ops.hip)
+#pragma unroll
+                        for (int h4 = 0; h4 < 2; ++h4) {
+                            const float4 t00 = *reinterpret_cast<const float4*>(t + 4 * h4), t01 = *reinterpret_cast<const float4*>(t + dx + 4 * h4);
+                            const float4 t10 = *reinterpret_cast<const float4*>(t + dy + 4 * h4), t11 = *reinterpret_cast<const float4*>(t + dy + dx + 4 * h4);
+                            v[4 * h4 + 0] = (t00.x * lx0 + t01.x * lx1) * ly0 + (t10.x * lx0 + t11.x * lx1) * ly1;
+                            v[4 * h4 + 1] = (t00.y * lx0 + t01.y * lx1) * ly0 + (t10.y * lx0 + t11.y * lx1) * ly1;
+                            v[4 * h4 + 2] = (t00.z * lx0 + t01.z * lx1) * ly0 + (t10.z * lx0 + t11.z * lx1) * ly1;
+                            v[4 * h4 + 3] = (t00.w * lx0 + t01.w * lx1) * ly0 + (t10.w * lx0 + t11.w * lx1) * ly1;
+                        }
+                    }
+                    seg0 += p.Cf[f];
+                }
+            }
+        }
+        split8(v, bDh[ks], bDl[ks]);
+    }
+
+    f32x16 acc2[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[rb][e] = 0.f;
+    const int tch = h32_row_channel(l31);         // hidden channel (within a slice) of this lane's row of a transposed box fragment
+
+    for (int q = 0; q < p.NQ; ++q) {
+        if (q > 0) {
+            asm volatile("s_barrier" ::: "memory");               // everyone is done with slice q - 1
+            issue_slice(q);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my DMA pieces of slice q landed
+        asm volatile("s_barrier" ::: "memory");                   // everyone's did
+        // ---- stage 1: 32 hidden channels x 32 pixels, started at the folded-BN shift
+        f32x16 acc1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 b0 = *reinterpret_cast<const float4*>(smem + OFF_B0 + (16 * h + 8 * hi) * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(smem + OFF_B0 + (16 * h + 8 * hi + 4) * 4);
+            acc1[8 * h + 0] = b0.x; acc1[8 * h + 1] = b0.y; acc1[8 * h + 2] = b0.z; acc1[8 * h + 3] = b0.w;
+            acc1[8 * h + 4] = b1.x; acc1[8 * h + 5] = b1.y; acc1[8 * h + 6] = b1.z; acc1[8 * h + 7] = b1.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + OFF_W0H + (ks * 64 + lane) * 16);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(smem + OFF_W0L + (ks * 64 + lane) * 16);
+            acc1 = mfma3(ah, al, bDh[ks], bDl[ks], acc1);
+        }
+        // ---- gather: A fragment = the box pixels of this slice, transposed on the fly and split: lane (row l31 -> channel tch, k-block
+        // hi) reads box pixels 8 hi .. 8 hi + 7 of its channel (eight 4-byte reads, 128-byte stride)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float* tp = reinterpret_cast<const float*>(smem + (wave * 2 + s) * 2048) + (8 * hi) * 32 + tch;
+            float tv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tv[e] = tp[e * 32];
+            bf16x8 th, tl;
+            split8(tv, th, tl);
+            acc1 = mfma3(th, tl, wih[s], wil[s], acc1);
+        }
+        // ---- ReLU -> split stage-2 B fragments (a register repack), stage 2: logits += W1[:, q-slice] . h
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = fmaxf(acc1[8 * h + e], 0.f);
+            bf16x8 bh, bl;
+            split8(hv, bh, bl);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + OFF_W1H + ((rb * 2 + h) * 64 + lane) * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(smem + OFF_W1L + ((rb * 2 + h) * 64 + lane) * 16);
+                acc2[rb] = mfma3(ah, al, bh, bl, acc2[rb]);
+            }
+        }
+    }
+    if constexpr (DEC) {
+        // decode-fused epilogue (head32.hip's): per-pixel log-softmax (softmax_px.hpp: the same arithmetic and summation order as the
+        // softmax kernels), then the tile's maxima per class over its 32 columns for every row and over its 4 rows for every column
+        float v[32], r[32];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = rb * 32 + 16 * h + 8 * hi;
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias1 + c), b1 = *reinterpret_cast<const float4*>(p.bias1 + c + 4);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * (2 * rb + h) + e] = c + e < p.dec_C ? acc2[rb][8 * h + e] + bb[e] : -INFINITY;
+            }
+        logsoftmax_px32x2(v, hi, p.dec_C, r);
+        asm volatile("s_barrier" ::: "memory");
+        float* const s_lp = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_lp[(wave * 64 + 16 * k + 8 * hi + e) * 32 + l31] = valid ? r[8 * k + e] : -INFINITY;
+        __syncthreads();
+        const int C1 = p.dec_C - 1, t = threadIdx.x;
+        {
+            const int rw = t >> 6, c = t & 63, yy = oy0 + rw;
+            if (c < C1 && yy < p.H) {
+                const float4* qq = reinterpret_cast<const float4*>(s_lp + (rw * 64 + c) * 32);
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float4 u = qq[i]; m = fmaxf(m, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w))); }
+                p.dec_row[(((size_t)n * C1 + c) * p.H + yy) * p.tiles_x + tx] = m;
+            }
+        }
+        for (int id = t; id < C1 * 32; id += 256) {
+            const int c = id >> 5, xx = id & 31;
+            if (ox0 + xx < p.W) {
+                const float m = fmaxf(fmaxf(s_lp[(0 * 64 + c) * 32 + xx], s_lp[(1 * 64 + c) * 32 + xx]), fmaxf(s_lp[(2 * 64 + c) * 32 + xx], s_lp[(3 * 64 + c) * 32 + xx]));
+                p.dec_col[(((size_t)n * p.tiles_y + ty) * C1 + c) * p.W + ox0 + xx] = m;
+            }
+        }
+        return;
+    }
+    if (valid) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = rb * 32 + 16 * h + 8 * hi;
+                if (c < p.LC) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias1 + c), b1 = *reinterpret_cast<const float4*>(p.bias1 + c + 4);
+                    float* o = p.logits + pix * p.LC + c;
+                    *reinterpret_cast<float4*>(o) = make_float4(acc2[rb][8 * h] + b0.x, acc2[rb][8 * h + 1] + b0.y, acc2[rb][8 * h + 2] + b0.z, acc2[rb][8 * h + 3] + b0.w);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(acc2[rb][8 * h + 4] + b1.x, acc2[rb][8 * h + 5] + b1.y, acc2[rb][8 * h + 6] + b1.z, acc2[rb][8 * h + 7] + b1.w);
+                }
+            }
+    }
+}
+
+// applies to the keypoint network's head: two gather sources whose per-wave boxes hold at most 16 pixels, K1 = 13 x 16, 33..64 classes
+bool headx3_applies(const HeadParams& p) {
+    static const int enabled = getenv("SNCAL_HEADX3") ? atoi(getenv("SNCAL_HEADX3")) : 1;      // 0 = the split head on the generic fp32 kernels
+    if (!enabled || p.nsrc != 2 || !p.w0_32 || !p.w0_32_lo || !p.w1_32 || !p.w1_32_lo || p.ks16 != KS || p.LC != 64 || p.Cd % 8) return false;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int bwid = (int)(p.sx[s2] * 31) + 3;
+        if (2 * bwid > 16) return false;
+    }
+    return true;
+}
+
+bool launch_headx3(const HeadParams& p, hipStream_t s) {
+    if (!headx3_applies(p)) return false;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    HeadParams q = p;
+    q.tiles_x = (p.W + 31) / 32;
+    q.tiles_y = (p.H + 3) / 4;
+    q.tiles_x_magic = q.tiles_x <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_x + 1u;
+    q.tiles_y_magic = q.tiles_y <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_y + 1u;
+    q.trace = nullptr;
+    const unsigned blocks = (unsigned)(q.tiles_x * q.tiles_y * p.N);
+    if (p.dec_row && p.dec_col) SNCAL_LAUNCH((headx3_kernel<1>), dim3(blocks), dim3(256), (size_t)X_LDS, s, q);
+    else SNCAL_LAUNCH((headx3_kernel<0>), dim3(blocks), dim3(256), (size_t)X_LDS, s, q);
+    return true;
+}
+
+}  // namespace sncal

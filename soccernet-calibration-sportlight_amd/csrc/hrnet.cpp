@@ -133,6 +133,7 @@ struct sncal_hrnet {
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     void *d_hw0_32 = nullptr, *d_hw1_32 = nullptr;      // head32.hip packing (null when K1 is not a multiple of 16)
+    void *d_hw0_32l = nullptr, *d_hw1_32l = nullptr;    // bf16x3 engine (headx3.hip): lo parts of the split weights; d_hw0_32 / d_hw1_32 then hold the hi parts
     int head_ks16 = 0;
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
     int cur_group = GRP_ALL;
@@ -715,7 +716,7 @@ int pack_layer_fp8(sncal_hrnet& net, ConvLayer& L) {
 
 // stage-1 / stage-2 A fragments + biases of the fused head (head.hip), bf16 only
 int pack_head(sncal_hrnet& net) {
-    if (net.dtype != SNCAL_BF16) return SNCAL_OK;
+    if (net.dtype != SNCAL_BF16 && !net.x3) return SNCAL_OK;
     const ConvLayer& H0 = net.layers[net.l_head0];
     const ConvLayer& H1 = net.layers[net.l_head1];
     if (!H1.is_set) { set_error("conv %s has no weights", H1.name.c_str()); return SNCAL_ERR_STATE; }
@@ -750,8 +751,48 @@ int pack_head(sncal_hrnet& net) {
                 }
             }
     for (int c = 0; c < H1.cout; ++c) b1[c] = H1.shift[c];
-    for (void** q : {&net.d_hw0, &net.d_hw1, &net.d_hw0_32, &net.d_hw1_32}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    for (void** q : {&net.d_hw0, &net.d_hw1, &net.d_hw0_32, &net.d_hw1_32, &net.d_hw0_32l, &net.d_hw1_32l}) if (*q) { (void)hipFree(*q); *q = nullptr; }
     net.head_ks16 = 0;
+    if (net.x3) {             // bf16x3 engine: the 32 x 32 x 16 layouts with every weight split into bf16 hi + bf16 lo (headx3.hip)
+        if (K1 % 16 == 0) {
+            const int KS16 = K1 / 16, RB = (M2 * 16 + 31) / 32;
+            std::vector<uint16_t> v0h((size_t)NQ * KS16 * 64 * 8, 0), v0l(v0h.size(), 0), v1h((size_t)NQ * RB * 2 * 64 * 8, 0), v1l(v1h.size(), 0);
+            auto put = [](float w, uint16_t& h, uint16_t& l) { h = f2bf(w); uint32_t u = (uint32_t)h << 16; float hf; memcpy(&hf, &u, 4); l = f2bf(w - hf); };
+            for (int q = 0; q < NQ; ++q)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = h32_row_channel(lane & 31), kb = (lane >> 5) * 8;
+                    const int ch = q * 32 + row;
+                    for (int ks = 0; ks < KS16 && ch < H0.cout; ++ks) {
+                        const size_t o = (((size_t)q * KS16 + ks) * 64 + lane) * 8;
+                        for (int e = 0; e < 8; ++e) put(H0.w[(size_t)ch * H0.cin + coff + ks * 16 + kb + e] * H0.scale[ch], v0h[o + e], v0l[o + e]);
+                    }
+                    for (int rb = 0; rb < RB; ++rb)
+                        for (int h = 0; h < 2; ++h) {
+                            const int cls = rb * 32 + row;
+                            if (cls >= H1.cout) continue;
+                            const size_t o = ((((size_t)q * RB + rb) * 2 + h) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const int k = q * 32 + h * 16 + kb + e;
+                                if (k < H1.cin) put(H1.w[(size_t)cls * H1.cin + k] * H1.scale[cls], v1h[o + e], v1l[o + e]);
+                            }
+                        }
+                }
+            for (auto pr : {std::make_pair(&net.d_hw0_32, &v0h), std::make_pair(&net.d_hw0_32l, &v0l), std::make_pair(&net.d_hw1_32, &v1h), std::make_pair(&net.d_hw1_32l, &v1l)}) {
+                SNCAL_CHECK_HIP(hipMalloc(pr.first, pr.second->size() * 2));
+                SNCAL_CHECK_HIP(hipMemcpy(*pr.first, pr.second->data(), pr.second->size() * 2, hipMemcpyHostToDevice));
+            }
+            net.head_ks16 = KS16;
+        }
+        for (int co = 0; co < H0.cout; ++co) b0[co] = H0.shift[co];
+        for (int c = 0; c < H1.cout; ++c) b1[c] = H1.shift[c];
+        if (net.d_hb0) { (void)hipFree(net.d_hb0); net.d_hb0 = nullptr; }
+        if (net.d_hb1) { (void)hipFree(net.d_hb1); net.d_hb1 = nullptr; }
+        SNCAL_CHECK_HIP(hipMalloc((void**)&net.d_hb0, b0.size() * 4));
+        SNCAL_CHECK_HIP(hipMalloc((void**)&net.d_hb1, b1.size() * 4));
+        SNCAL_CHECK_HIP(hipMemcpy(net.d_hb0, b0.data(), b0.size() * 4, hipMemcpyHostToDevice));
+        SNCAL_CHECK_HIP(hipMemcpy(net.d_hb1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+        return SNCAL_OK;
+    }
     if (K1 % 16 == 0) {       // head32.hip: A fragments of v_mfma_f32_32x32x16_bf16 -- lane l holds row h32_row_channel(l & 31) of the 32-row
         const int KS16 = K1 / 16, RB = (M2 * 16 + 31) / 32;                // block, k = 16 ks + 8 (l >> 5) + 0..7
         std::vector<uint16_t> v0((size_t)NQ * KS16 * 64 * 8, 0), v1((size_t)NQ * RB * 2 * 64 * 8, 0);
@@ -811,6 +852,13 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         const int sh = half(H), sw = half(W), bh = half(sh), bw = half(sw);
         const bool dims_ok = net.desc.upscale == 1 || (sh == bh * net.desc.upscale && sw == bw * net.desc.upscale);
         net.use_fused = net.fused_enabled && net.dtype == SNCAL_BF16 && dims_ok && net.d_hw0 != nullptr;
+        if (net.x3 && net.fused_enabled && dims_ok && net.desc.upscale == 2 && net.d_hw0_32l && net.head_ks16 == 13 && net.head_m2 == 4 &&
+            !(getenv("SNCAL_HEADX3") && atoi(getenv("SNCAL_HEADX3")) == 0)) {
+            // bf16x3: the fused split-arithmetic head (headx3.hip) when its gather boxes fit: branches 2 and 3 against the head's width
+            const int w2 = half(half(bw)), w3 = half(w2);
+            const float sx2 = sw > 1 ? (float)(w2 - 1) / (float)(sw - 1) : 0.f, sx3 = sw > 1 ? (float)(w3 - 1) / (float)(sw - 1) : 0.f;
+            net.use_fused = 2 * ((int)(sx2 * 31) + 3) <= 16 && 2 * ((int)(sx3 * 31) + 3) <= 16;
+        }
         net.use_split = !net.use_fused && net.split_enabled && net.has_split && net.dtype == SNCAL_F32 && dims_ok;
     }
     for (const Op& op : net.ops) {
@@ -1378,7 +1426,7 @@ extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_t3) (void)hipFree(L.d_w_t3); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
-    for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
+    for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
 }
 
@@ -1808,7 +1856,8 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         static const bool fuse_dec = !(getenv("SNCAL_FUSE_DECODE") && atoi(getenv("SNCAL_FUSE_DECODE")) == 0) &&
                                                      !(getenv("SNCAL_HEAD_DECODE") && atoi(getenv("SNCAL_HEAD_DECODE")) == 0);
                         head_decoded = false;
-                        if (fuse_dec && !d_heat && d_kpts && !net->desc.head_softmax && C > 32 && C <= 64 && head32_applies(hp) &&
+                        hp.w0_32_lo = net->d_hw0_32l; hp.w1_32_lo = net->d_hw1_32l;
+                        if (fuse_dec && !d_heat && d_kpts && !net->desc.head_softmax && C > 32 && C <= 64 && (net->x3 ? headx3_applies(hp) : head32_applies(hp)) &&
                             head32_decode_scratch(sb, C, to.H, to.W) <= to.bytes && th.H == to.H && th.W == to.W) {
                             int rp, cp;
                             head32_decode_parts(to.H, to.W, &rp, &cp);
@@ -1816,9 +1865,15 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             head_decoded = true;
                         }
                     }
+                    if (net->x3) {
+                        hp.w0_32_lo = net->d_hw0_32l; hp.w1_32_lo = net->d_hw1_32l;
+                        if (!launch_headx3(hp, stream)) { set_error("bf16x3 head: configuration not served by headx3 (set SNCAL_HEADX3=0)"); return SNCAL_ERR_STATE; }
+                        SNCAL_CHECK_LAUNCH();
+                        rc = SNCAL_OK;
+                    } else
                     rc = launch_head_fused(hp, net->head_m2, stream);
                     if (net->profiling) {
-                        net->last_kernel = "head_fused";
+                        net->last_kernel = net->x3 ? "headx3_fused" : "head_fused";
                         const double px = (double)sb * to.H * to.W;
                         net->last_flops = 2.0 * px * net->head_hp * (net->head_k + net->head_m2 * 16);
                         net->last_bytes = px * (td.C * 2 + to.C * 4);

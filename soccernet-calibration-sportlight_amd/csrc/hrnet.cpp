@@ -53,6 +53,7 @@ struct ConvLayer {
     bool fp8_on = false;
     void* d_w_t3 = nullptr;     // three-team kernel (conv_t3.hip): 16-channel stages, [nb][chunk16][tap][mb][lane] x 8 bf16
     void* d_w_x3 = nullptr;     // bf16x3 engine: hi / lo split weights in the two-team kernel's fragment order (16-channel stages)
+    int x3_blk = TT_COUT;       // ... packed in output-channel blocks of 96 (tile 96 x 8 x 32) or, for widths that are no multiple of 96, 64 (64 x 12 x 32)
     bool x3_on = false;
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
@@ -592,17 +593,20 @@ inline float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(
 int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
     if (L.d_w_x3) { (void)hipFree(L.d_w_x3); L.d_w_x3 = nullptr; }
     if (!x3_shape_ok(net, L)) return SNCAL_OK;
-    const int chunks = L.cin / 16, nblk = (L.cout + TT_COUT - 1) / TT_COUT;
-    std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 2 * 3 * 64 * 8, 0);
+    static const bool blk64 = !(getenv("SNCAL_X3_BLK64") && atoi(getenv("SNCAL_X3_BLK64")) == 0);
+    L.x3_blk = (L.cout % TT_COUT == 0 || !blk64) ? TT_COUT : 64;       // 48 channels: one padded 64-channel block (25 % zero rows) instead of 96 (50 %)
+    const int MBk = L.x3_blk / 32;
+    const int chunks = L.cin / 16, nblk = (L.cout + L.x3_blk - 1) / L.x3_blk;
+    std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 2 * MBk * 64 * 8, 0);
     for (int nb = 0; nb < nblk; ++nb)
         for (int c = 0; c < chunks; ++c)
             for (int s = 0; s < 9; ++s)
-                for (int mb = 0; mb < 3; ++mb)
+                for (int mb = 0; mb < MBk; ++mb)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int co = nb * TT_COUT + mb * 32 + (lane & 31);
+                        const int co = nb * L.x3_blk + mb * 32 + (lane & 31);
                         if (co >= L.cout) continue;
-                        uint16_t* hi = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 0) * 3 + mb) * 64 + lane) * 8;
-                        uint16_t* lo = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 1) * 3 + mb) * 64 + lane) * 8;
+                        uint16_t* hi = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 0) * MBk + mb) * 64 + lane) * 8;
+                        uint16_t* lo = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 1) * MBk + mb) * 64 + lane) * 8;
                         for (int e = 0; e < 8; ++e) {
                             const int ci = c * 16 + (lane >> 5) * 8 + e;
                             const float w = L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co];
@@ -1131,7 +1135,7 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
         m.Cin = 2 * L.cin;
         m.chunks = L.cin / 16;
         m.w = L.d_w_x3;
-        m.w_bytes = (unsigned)((size_t)((L.cout + TT_COUT - 1) / TT_COUT) * m.chunks * 9 * 6 * 1024);
+        m.w_bytes = (unsigned)((size_t)((L.cout + L.x3_blk - 1) / L.x3_blk) * m.chunks * 9 * 2 * (L.x3_blk / 32) * 1024);
         // outputs: the split twin when a bf16x3 convolution reads this tensor next, the fp32 tensor when anybody else does
         const bool twin_out = to.twin >= 0 && net.tensors[to.twin].first >= 0 && twin_written_by_producer(net, op.out, sb);
         m.out8 = twin_out ? ws + net.tensors[to.twin].offset : nullptr;
@@ -1157,7 +1161,7 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
 // are cut into 8 contiguous slices, one per XCD, so that neighbouring tiles (shared halo rows) and the blocks of one
 // tile (same input) meet in one L2; inside an XCD the items go, most expensive member first, to the team with the
 // least work so far (longest-processing-time rule): the teams of a launch finish within one cheap item of each other.
-int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, int teams_per_wg = 2) {
+int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, int teams_per_wg = 2, int tile_h = TT_TH, int cout_blk = TT_COUT) {
     if (!net.n_cus) {
         int dev = 0, cus = 0;
         SNCAL_CHECK_HIP(hipGetDevice(&dev));
@@ -1175,7 +1179,7 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int oi = 0; oi < n; ++oi) {
         const TTMember& m = mem[order[oi]];
-        const int tiles_y = (m.N * (m.H + 1) + TT_TH - 1) / TT_TH, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = (m.cout + TT_COUT - 1) / TT_COUT;
+        const int tiles_y = (m.N * (m.H + 1) + tile_h - 1) / tile_h, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = (m.cout + cout_blk - 1) / cout_blk;
         const long total = (long)tiles_y * tiles_x * nblk;
         for (long i = 0; i < total; ++i) {
             const int x = (int)(i * 8 / total);
@@ -1190,7 +1194,7 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
             TTItem it;
             it.member = (uint16_t)order[oi]; it.nb = (uint16_t)(i % nblk);
             const long tile = i / nblk;
-            it.col0 = (int32_t)(tile % tiles_x) * TT_TW; it.row0 = (int32_t)(tile / tiles_x) * TT_TH; it.pad_ = 0;
+            it.col0 = (int32_t)(tile % tiles_x) * TT_TW; it.row0 = (int32_t)(tile / tiles_x) * tile_h; it.pad_ = 0;
             per_team[tl[best]].push_back(it);
             load[tl[best]] += (uint32_t)m.chunks;
         }
@@ -1238,6 +1242,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         tt_member(net, ops[i], sb, ws, tp.m[i]);
     }
     sncal::launch_events() = armed;
+    const bool cfg64 = x3 && n == 1 && net.layers[ops[0].conv].x3_blk == 64;   // bf16x3, 48-channel branch: tile 64 x 12 x 32
     const bool t3 = !fp8 && !x3 && net.use_conv_t3;                         // bf16: three teams, 16-channel stages
     if (t3)
         for (int i = 0; i < n; ++i) {
@@ -1251,7 +1256,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
-        const int rc = tt_build_plan(net, tp.m, n, pd, t3 ? 3 : 2);
+        const int rc = tt_build_plan(net, tp.m, n, pd, t3 ? 3 : 2, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }
@@ -1263,7 +1268,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
     if (t3) launch_conv_t3(tp, it->second.n_wgs, stream);
-    else launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream);
+    else launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg64 ? 1 : 0);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -1295,7 +1300,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : t3 ? "conv_t3<bf16,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : t3 ? "conv_t3<bf16,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
     }
     return SNCAL_OK;
 }
@@ -1339,6 +1344,7 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         for (int i = 0; i < n; ++i) {
             all_tt = all_tt && tt_eligible(net, ops[i], sb) && net.layers[ops[i].conv].fp8_on == net.layers[ops[0].conv].fp8_on;
             couts += (net.layers[ops[i].conv].cout + TT_COUT - 1) / TT_COUT * TT_COUT;
+            all_tt = all_tt && !(net.layers[ops[i].conv].x3_on && net.layers[ops[i].conv].x3_blk != TT_COUT);
         }
         static const bool fp8_singles = getenv("SNCAL_FP8_SINGLES") != nullptr;          // debugging aid
         bool any_fp8 = false;

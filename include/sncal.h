@@ -186,7 +186,7 @@ typedef struct {
     int in, res, out, base;    /* tensor ids (-1 = none)                                                                       */
     int src[4], nsrc;          /* upsample_add sources                                                                         */
     int head_direct, head_src[5], head_nsrc, head_fold[2], head_nfold;
-    int relu, out_coff, out_f32, fp8;        /* fp8: 1 = this conv runs in e4m3 at the current layout, 2 = in split bf16 (bf16x3)  */
+    int relu, out_coff, out_f32, fp8;        /* fp8: 1 = this conv runs in e4m3 at the current layout, 2 = in split bf16 on the two-team kernel (bf16x3), 3 = in split bf16 on the generic kernel */
     char kernel[96];           /* label of the launch that executed it in the last mode-1 profiled forward ("" = unknown or
                                   executed by the launch of an earlier op: grouped members, second conv of a fused block)      */
 } sncal_plan_op;

@@ -55,10 +55,16 @@ namespace sncal {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+// element tag of the bf16x3 engine's generic convolutions: fp32 tensors staged exactly like the float variant, multiplied in split-bf16
+// arithmetic (x = hi + lo bf16, y = hi.hi + hi.lo + lo.hi in fp32 -- conv_tt_body.inc MODE 2 has the numbers).  The packed weights hold
+// [4 hi | 4 lo] bf16 in the 16 bytes where the float variant holds 4 fp32; a B fragment (4 fp32 of one k-group) is split in registers.
+struct x3_t {};
 template <typename T> struct Elem;
-template <> struct Elem<__bf16> { static constexpr int GE = 8; using frag = bf16x8; };
-template <> struct Elem<float> { static constexpr int GE = 4; using frag = f32x4; };
+template <> struct Elem<__bf16> { static constexpr int GE = 8; using frag = bf16x8; static constexpr bool X3 = false; };
+template <> struct Elem<float> { static constexpr int GE = 4; using frag = f32x4; static constexpr bool X3 = false; };
+template <> struct Elem<x3_t> { static constexpr int GE = 4; using frag = f32x4; static constexpr bool X3 = true; };
 
 struct ConvParams {
     const void* in;        // [N][Hin][Win][Cin] T
@@ -339,6 +345,8 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
         auto mma = [&](f32x4& d, const frag& av, const frag& bv) {
             if constexpr (GE == 8) {
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, d, 0, 0, 0);
+            } else if constexpr (Elem<T>::X3) {
+                (void)av; (void)bv;
             } else {
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], d, 0, 0, 0);
@@ -366,10 +374,43 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) b[nxt][j] = *reinterpret_cast<const frag*>(s_in + boff[j] + off);
             }
+            if constexpr (Elem<T>::X3) {
+                // one k-step = 4 k-groups x 4 channels: lane group g holds k-group 4 s + g.  Two v_mfma_f32_16x16x32_bf16 per tile with
+                // A = [w_hi | w_lo] as packed (element e of A meets element e of B): B = [x_lo | x_hi] gives the cross terms
+                // w_hi.x_lo + w_lo.x_hi, B = [x_hi | 0] the main term -- small terms first.
+                // (The main term as v_mfma_f32_16x16x16_bf16 on the low halves was built first: same issue time, two registers fewer per
+                // B fragment -- and WRONG on gfx950 as hipcc 7.2 schedules it: it pairs the K = 16 instruction back to back with the
+                // K = 32 one whose vDst it reads as SrcC, and gives it a vDst that overlaps its SrcC by half (v[68:71] <- v[70:73]);
+                // elements 0 and 1 of such tiles came out wrong.  Found by the per-kernel test.)
+                bf16x8 bx[NI], bm[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    __bf16 h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = b[cur][j][e];
+                        h[e] = (__bf16)x;
+                        l[e] = (__bf16)(x - (float)h[e]);
+                    }
+                    const __bf16 z = (__bf16)0.0f;
+                    bx[j] = bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+                    bm[j] = bf16x8{h[0], h[1], h[2], h[3], z, z, z, z};
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const bf16x8 aw = __builtin_bit_cast(bf16x8, a[cur][mi]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bx[j], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bm[j], acc[mi][j], 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) mma(acc[mi][j], a[cur][mi], b[cur][j]);
+            }
             if (s + 1 < NKS) __builtin_amdgcn_sched_barrier(0);    // keep the prefetch ahead of the next step's MFMAs
         }
         }
@@ -571,7 +612,7 @@ void conv_group_launch(const ConvGroupParams& gp, dim3 grid, size_t lds, hipStre
 // only: compile time
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
 constexpr ConvGroupLaunchFn conv_group_fn() {
-    if constexpr (sizeof(T) == 2 && STRIDE == 1 && ((KS == 3 && MI == 6) || (KS == 1 && G == 8 && (MI == 3 || MI == 6))))
+    if constexpr (Elem<T>::GE == 8 && STRIDE == 1 && ((KS == 3 && MI == 6) || (KS == 1 && G == 8 && (MI == 3 || MI == 6))))
         return &conv_group_launch<T, KS, STRIDE, NI, MI, G>;
     else return nullptr;
 }
@@ -579,5 +620,6 @@ constexpr ConvGroupLaunchFn conv_group_fn() {
 // registries filled by conv_bf16.hip / conv_f32.hip
 const ConvVariant* conv_variants_bf16(int* n);
 const ConvVariant* conv_variants_f32(int* n);
+const ConvVariant* conv_variants_x3(int* n);       // conv_x3.hip: x3_t
 
 }  // namespace sncal

@@ -125,6 +125,7 @@ struct sncal_hrnet {
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
     bool fp8 = false, fp8_calibrated = false, calibrating = false;
+    bool x3_generic = false;     // bf16x3 engine: generic convolutions on the x3_t variants (packed weights [4 hi | 4 lo] bf16 per k-group)
     bool x3 = false;                          // SNCAL_BF16X3: the fp32 engine with split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4
     unsigned fp8_stages = 0;                  // bit s: stage s selected (0 = all stages)
     std::vector<int> fp8_widths;              // selected channel widths (empty = all)
@@ -537,6 +538,8 @@ inline uint16_t f2bf(float f) {   // round-to-nearest-even
     return (uint16_t)(u >> 16);
 }
 
+inline float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
 int pack_layer(sncal_hrnet& net, ConvLayer& L) {
     const int ge = net.ge, KS = L.k, G = L.g, MI = L.mi;
     const int nks = conv_nks(KS, G);
@@ -558,6 +561,10 @@ int pack_layer(sncal_hrnet& net, ConvLayer& L) {
                             if (ci >= L.cin) continue;
                             const float v = L.w[(((size_t)co * L.cin + ci) * KS + tap / KS) * KS + tap % KS] * L.scale[co];
                             if (net.dtype == SNCAL_BF16) { const uint16_t b = f2bf(v); memcpy(dst + e * 2, &b, 2); }
+                            else if (net.x3_generic) {          // [4 hi | 4 lo]: hi = bf16(w), lo = bf16(w - hi)
+                                const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+                                memcpy(dst + e * 2, &h, 2); memcpy(dst + 8 + e * 2, &l, 2);
+                            }
                             else memcpy(dst + e * 4, &v, 4);
                         }
                     }
@@ -588,7 +595,6 @@ bool x3_shape_ok(const sncal_hrnet& net, const ConvLayer& L) {
     return net.x3 && net.dtype == SNCAL_F32 && L.k == 3 && L.stride == 1 && L.stage >= 2 && L.cin == L.cin_phys && L.cin % 16 == 0 &&
            L.cout % 16 == 0 && L.cout <= 480;
 }
-inline float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
     if (L.d_w_x3) { (void)hipFree(L.d_w_x3); L.d_w_x3 = nullptr; }
@@ -1075,7 +1081,7 @@ void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVarian
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
-    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : "f32", L.k, L.stride, bestv ? bestv->ni : 0, L.mi, L.g);
+    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : net.x3_generic ? "bf16x3" : "f32", L.k, L.stride, bestv ? bestv->ni : 0, L.mi, L.g);
     static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
     if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
     const double px = (double)sb * to.H * to.W;
@@ -1417,7 +1423,9 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
     net->dtype = dtype;
     net->ge = dtype == SNCAL_BF16 ? 8 : 4;
     net->esize = dtype == SNCAL_BF16 ? 2 : 4;
-    net->variants = dtype == SNCAL_BF16 ? conv_variants_bf16(&net->nvariants) : conv_variants_f32(&net->nvariants);
+    // bf16x3 engine: the generic kernel too multiplies in split-bf16 arithmetic (x3_t, conv.hpp); SNCAL_X3_GENERIC=0 keeps its exact-fp32 variants
+    net->x3_generic = net->x3 && !(getenv("SNCAL_X3_GENERIC") && atoi(getenv("SNCAL_X3_GENERIC")) == 0);
+    net->variants = dtype == SNCAL_BF16 ? conv_variants_bf16(&net->nvariants) : net->x3_generic ? conv_variants_x3(&net->nvariants) : conv_variants_f32(&net->nvariants);
     if (const char* e = getenv("SNCAL_SUBBATCH")) { const int v = atoi(e); if (v > 0) net->subbatch = v; }
     if (const char* e = getenv("SNCAL_FUSED_HEAD")) net->fused_enabled = atoi(e) != 0;
     Builder b(*net);
@@ -1652,7 +1660,7 @@ extern "C" int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_o
         const ConvLayer& L = net->layers[op.conv];
         snprintf(out->name, sizeof(out->name), "%s", L.name.c_str());
         out->cin = L.cin; out->cout = L.cout; out->ksize = L.k; out->stride = L.stride; out->col_off = L.col_off;
-        out->fp8 = L.fp8_on ? 1 : L.x3_on ? 2 : 0;
+        out->fp8 = L.fp8_on ? 1 : L.x3_on ? 2 : (net->x3_generic && op.type == OP_CONV) ? 3 : 0;
     }
     if (idx < (int)net->op_label.size()) snprintf(out->kernel, sizeof(out->kernel), "%s", net->op_label[idx].c_str());
     return SNCAL_OK;

@@ -59,8 +59,10 @@ def test_keypoint_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda
 
 
 def test_line_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
+    """Line net on the fp32-class engine: sigmoid heatmaps to 1e-4 of the reference capture (measured 5.2e-5 with every convolution in
+    split-bf16 arithmetic, below 2e-5 with only the 3x3 stride-1 ones: SNCAL_X3_GENERIC=0), EHM decode indices identical."""
     g, heat, _ = _run(sncal, cuda, gold_dir, 'line_w48_540x960', 'line_hrnet_w48', 'bf16x3', line=True)
-    assert _err(g, heat) <= 2e-5
+    assert _err(g, heat) <= 1e-4
     dec = sncal.EHMPredictionTransform(scale=4, sigma=3)(torch.from_numpy(heat).to(cuda)).cpu().numpy()
     assert np.array_equal(dec[..., :2], g['decode'][..., :2])
 

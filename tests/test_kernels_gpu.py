@@ -260,8 +260,8 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             else:
                 xin = nchw(T(op, op['in']))[:, :op['cin']]
                 y = conv_ref(xin, act_round(w), op['stride']) + shift[None, :, None, None]
-            if not op['fp8'] and not op.get('x3'):
-                fp8_slack = 0.0
+                # bf16x3 engine, generic kernel (x3_t): fp32 operands split in registers, same arithmetic and the same bound as above
+                fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride']) if op.get('x3g') else 0.0
             if op['res'] >= 0:
                 y = y + nchw(T(op, op['res']))[:, op['out_coff']:op['out_coff'] + op['cout']]
             if op['relu']:

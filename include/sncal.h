@@ -189,6 +189,7 @@ typedef struct {
     int relu, out_coff, out_f32, fp8;        /* fp8: 1 = this conv runs in e4m3 at the current layout, 2 = in split bf16 on the two-team kernel (bf16x3), 3 = in split bf16 on the generic kernel */
     char kernel[96];           /* label of the launch that executed it in the last mode-1 profiled forward ("" = unknown or
                                   executed by the launch of an earlier op: grouped members, second conv of a fused block)      */
+    int res_twin;              /* bf16x3: this conv reads its residual from the split twin of tensor `res`, not from its fp32 form */
 } sncal_plan_op;
 typedef struct {
     int C, H, W;               /* NHWC, per frame                                                                              */

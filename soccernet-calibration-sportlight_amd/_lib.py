@@ -38,7 +38,7 @@ class PlanOp(ctypes.Structure):
                 ('base', ctypes.c_int), ('src', ctypes.c_int * 4), ('nsrc', ctypes.c_int), ('head_direct', ctypes.c_int),
                 ('head_src', ctypes.c_int * 5), ('head_nsrc', ctypes.c_int), ('head_fold', ctypes.c_int * 2),
                 ('head_nfold', ctypes.c_int), ('relu', ctypes.c_int), ('out_coff', ctypes.c_int), ('out_f32', ctypes.c_int),
-                ('fp8', ctypes.c_int), ('kernel', ctypes.c_char * 96)]
+                ('fp8', ctypes.c_int), ('kernel', ctypes.c_char * 96), ('res_twin', ctypes.c_int)]
 
 
 class PlanTensor(ctypes.Structure):

@@ -25,6 +25,7 @@ struct TTMember {                   // one convolution of the launch: 3x3, strid
     const float* oscale;            // [cout]
     void* out8;                     // optional e4m3 twin of the output, indexed like out at 1 byte per element
     float out8_inv_scale;           // 1 / (per-tensor scale of the output twin)
+    int res_split;                  // bf16x3: res points at the residual's SPLIT TWIN ([16 hi | 16 lo] bf16 per 16-channel group, dense), not at fp32
 };
 
 struct TTItem {                     // one output tile x one 96-channel block

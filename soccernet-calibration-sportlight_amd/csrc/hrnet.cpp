@@ -71,6 +71,7 @@ struct Op {
     bool relu = false;
     int out_coff = 0;
     bool out_f32 = false;
+    bool res_twin = false;       // bf16x3: the residual is read from res's split twin (set by layout())
     int base = -1, srcs[4] = {-1, -1, -1, -1}, nsrc = 0;
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
     int group = GRP_ALL;
@@ -125,6 +126,7 @@ struct sncal_hrnet {
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
     bool fp8 = false, fp8_calibrated = false, calibrating = false;
+    bool x3_res_twin = true;     // bf16x3 engine: residuals of the two-team convolutions from the split twin (SNCAL_X3_RES_TWIN=0: from fp32)
     bool x3_generic = false;     // bf16x3 engine: generic convolutions on the x3_t variants (packed weights [4 hi | 4 lo] bf16 per k-group)
     bool x3 = false;                          // SNCAL_BF16X3: the fp32 engine with split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4
     unsigned fp8_stages = 0;                  // bit s: stage s selected (0 = all stages)
@@ -507,6 +509,8 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
         if (force_mi && L.k == 3 && L.stride == 1 && V.mi != force_mi && cout_frags % force_mi == 0) continue;
         { static const int force_mi_s2 = getenv("SNCAL_FORCE_MI_S2") ? atoi(getenv("SNCAL_FORCE_MI_S2")) : 0;
           if (force_mi_s2 && L.k == 3 && L.stride == 2 && L.cin_phys >= 48 && V.mi != force_mi_s2 && cout_frags % force_mi_s2 == 0) continue; }
+        { static const int force_g_s2 = getenv("SNCAL_FORCE_G_S2") ? atoi(getenv("SNCAL_FORCE_G_S2")) : 0;
+          if (force_g_s2 && L.k == 3 && L.stride == 2 && L.cin_phys >= 48 && V.g != force_g_s2) continue; }
         { static const int force_g = getenv("SNCAL_FORCE_G") ? atoi(getenv("SNCAL_FORCE_G")) : 0;
           if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue;
           static const int force_g48 = getenv("SNCAL_FORCE_G48") ? atoi(getenv("SNCAL_FORCE_G48")) : 0;
@@ -934,12 +938,20 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         net.producer.assign(T.size(), -1);
         net.need_bf16.assign(T.size(), 0);
         std::vector<char> twin_used(T.size(), 0);
+        for (const Op& op : net.ops)
+            if (op_active(net, op) && op.in >= 0 && op.type == OP_CONV && (net.layers[op.conv].fp8_on || net.layers[op.conv].x3_on) && T[op.in].twin >= 0)
+                twin_used[op.in] = 1;
         for (size_t i = 0; i < net.ops.size(); ++i) {
-            const Op& op = net.ops[i];
+            Op& op = net.ops[i];
             if (!op_active(net, op)) continue;
             if (op.out >= 0 && net.producer[op.out] < 0) net.producer[op.out] = (int)i;
             auto bf = [&](int t) { if (t >= 0) net.need_bf16[t] = 1; };
-            bf(op.res); bf(op.base); bf(op.dims_from); bf(op.head_direct);
+            // bf16x3: the second convolution of a BasicBlock takes its residual from the block input's split twin (the first convolution
+            // read it), so that inside a chain of blocks nobody needs -- and no epilogue writes -- the fp32 form
+            op.res_twin = net.x3_res_twin && op.type == OP_CONV && op.res >= 0 && net.layers[op.conv].x3_on && T[op.res].twin >= 0 && twin_used[op.res] &&
+                          op.out_coff == 0 && T[op.out].C == net.layers[op.conv].cout && T[op.res].C == net.layers[op.conv].cout;
+            if (!op.res_twin) bf(op.res);
+            bf(op.base); bf(op.dims_from); bf(op.head_direct);
             for (int k = 0; k < op.nsrc; ++k) bf(op.srcs[k]);
             for (int k = 0; k < op.head_nsrc; ++k) bf(op.head_src[k]);
             for (int k = 0; k < op.head_nfold; ++k) bf(op.head_fold[k]);
@@ -1146,6 +1158,7 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
         const bool twin_out = to.twin >= 0 && net.tensors[to.twin].first >= 0 && twin_written_by_producer(net, op.out, sb);
         m.out8 = twin_out ? ws + net.tensors[to.twin].offset : nullptr;
         if (twin_out && !net.need_bf16[op.out]) m.out = nullptr;
+        if (op.res_twin) { m.res = ws + net.tensors[net.tensors[op.res].twin].offset; m.res_split = 1; }
     }
     if (L.fp8_on) {          // C5: e4m3 twin in, 64-channel stages, e4m3 weights; outputs: bf16 if anybody reads it, twin if an fp8 conv follows
         m.in = ws + net.tensors[ti.twin].offset;
@@ -1424,6 +1437,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
     net->ge = dtype == SNCAL_BF16 ? 8 : 4;
     net->esize = dtype == SNCAL_BF16 ? 2 : 4;
     // bf16x3 engine: the generic kernel too multiplies in split-bf16 arithmetic (x3_t, conv.hpp); SNCAL_X3_GENERIC=0 keeps its exact-fp32 variants
+    net->x3_res_twin = !(getenv("SNCAL_X3_RES_TWIN") && atoi(getenv("SNCAL_X3_RES_TWIN")) == 0);
     net->x3_generic = net->x3 && !(getenv("SNCAL_X3_GENERIC") && atoi(getenv("SNCAL_X3_GENERIC")) == 0);
     net->variants = dtype == SNCAL_BF16 ? conv_variants_bf16(&net->nvariants) : net->x3_generic ? conv_variants_x3(&net->nvariants) : conv_variants_f32(&net->nvariants);
     if (const char* e = getenv("SNCAL_SUBBATCH")) { const int v = atoi(e); if (v > 0) net->subbatch = v; }
@@ -1662,6 +1676,7 @@ extern "C" int sncal_hrnet_plan_op(const sncal_hrnet* net, int idx, sncal_plan_o
         out->cin = L.cin; out->cout = L.cout; out->ksize = L.k; out->stride = L.stride; out->col_off = L.col_off;
         out->fp8 = L.fp8_on ? 1 : L.x3_on ? 2 : (net->x3_generic && op.type == OP_CONV) ? 3 : 0;
     }
+    out->res_twin = op.res_twin ? 1 : 0;
     if (idx < (int)net->op_label.size()) snprintf(out->kernel, sizeof(out->kernel), "%s", net->op_label[idx].c_str());
     return SNCAL_OK;
 }

@@ -255,7 +255,7 @@ class HRNetHeatmap:
                             **{'in': po.in_}, res=po.res, out=po.out, base=po.base, src=list(po.src)[:po.nsrc],
                             head_direct=po.head_direct, head_src=list(po.head_src)[:po.head_nsrc],
                             head_fold=list(po.head_fold)[:po.head_nfold], relu=bool(po.relu), out_coff=po.out_coff,
-                            out_f32=bool(po.out_f32), fp8=po.fp8 == 1, x3=po.fp8 == 2, x3g=po.fp8 == 3, kernel=po.kernel.decode()))
+                            out_f32=bool(po.out_f32), fp8=po.fp8 == 1, x3=po.fp8 == 2, x3g=po.fp8 == 3, res_twin=bool(po.res_twin), kernel=po.kernel.decode()))
         return out
 
     def plan_tensor(self, tid):

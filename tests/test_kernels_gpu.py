@@ -262,7 +262,12 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 y = conv_ref(xin, act_round(w), op['stride']) + shift[None, :, None, None]
                 # bf16x3 engine, generic kernel (x3_t): fp32 operands split in registers, same arithmetic and the same bound as above
                 fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride']) if op.get('x3g') else 0.0
-            if op['res'] >= 0:
+            if op['res'] >= 0 and op.get('res_twin'):
+                # bf16x3, inside a BasicBlock chain: the block input lives only as the split twin its first convolution read
+                raw = T(op, net.plan_tensor(op['res'])['twin'])
+                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                y = y + (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
+            elif op['res'] >= 0:
                 y = y + nchw(T(op, op['res']))[:, op['out_coff']:op['out_coff'] + op['cout']]
             if op['relu']:
                 y = torch.relu(y)
@@ -327,7 +332,7 @@ def _bf16_written(net, ops, op):
     for o in ops:
         if not o['active'] or o['idx'] <= op['idx']:
             continue
-        readers = [o['res'], o['base'], o['head_direct']] + o['src'] + o['head_src'] + o['head_fold']
+        readers = [-1 if o.get('res_twin') else o['res'], o['base'], o['head_direct']] + o['src'] + o['head_src'] + o['head_fold']
         if t in readers:
             return True
         if o['in'] == t and not (o['type'] == 'conv' and (o['fp8'] or o.get('x3'))):
@@ -476,5 +481,5 @@ def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
     _report(stats, 'bf16x3_w48_540p')
     k, k48 = 'conv_tt<bf16x3,k3,s1,8x32x96>', 'conv_tt<bf16x3,k3,s1,12x32x64>'   # 144 wide + 64 48-channel convolutions, each checked on its fp32 output, its twin, or both
     n = lambda key: stats.get(key, {'ops': 0})['ops']
-    assert n(k) + n(k48) >= 100 and n(k + ' split out') + n(k48 + ' split out') >= 150
+    assert n(k) + n(k48) >= 20 and n(k + ' split out') + n(k48 + ' split out') >= 150      # (fp32 outputs: module ends only)
     assert n(k) + n(k + ' split out') >= 144 and n(k48) + n(k48 + ' split out') >= 64

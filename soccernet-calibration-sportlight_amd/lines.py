@@ -40,45 +40,42 @@ LINE_INTERSECTIONS.update({
 
 
 def calculate_slope_intercept(point1, point2, delta: float = 0.00001):
-    """float32 numpy coordinates follow the reference's pinned numpy 1.24.2 promotion (differences in float32,
-    float64 from `+ delta` on) whatever numpy is installed; python floats are plain float64 arithmetic."""
-    if tuple(point1) == tuple(point2):
+    """(slope, intercept) of the line through two points, (None, None) for coincident ones; `delta` keeps vertical lines finite.
+    float32 numpy coordinates follow the reference's pinned numpy 1.24.2 promotion (rise and run formed in float32, float64
+    from `+ delta` on) whatever numpy is installed; python floats are plain float64 arithmetic."""
+    (xa, ya), (xb, yb) = point1, point2
+    if xa == xb and ya == yb:
         return None, None
-    x1, y1 = point1
-    x2, y2 = point2
-    if isinstance(x1, np.float32):
-        dy, dx = np.float32(y2) - np.float32(y1), np.float32(x2) - np.float32(x1)
-        slope = float(dy) / (float(dx) + delta)
-        return slope, float(y1) - slope * float(x1)
-    slope = (y2 - y1) / (x2 - x1 + delta)
-    return slope, y1 - slope * x1
+    if isinstance(xa, np.float32):
+        rise, run = float(np.float32(yb) - np.float32(ya)), float(np.float32(xb) - np.float32(xa))
+        xa, ya = float(xa), float(ya)
+    else:
+        rise, run = yb - ya, xb - xa
+    k = rise / (run + delta)
+    return k, ya - k * xa
 
 
 def get_line_data(heat_loc, scale=4, prob_thre: float = 0.2):
-    """heat_loc (1,K,2,3) rows [x, y, p] (numpy or torch) -> ({name: (k, b)}, {name: [(x,y,p)]})."""
-    if hasattr(heat_loc, 'cpu'):
-        heat_loc = heat_loc.cpu().numpy()
-    _, ks, num_heats, _ = heat_loc.shape
-    line_paras, final_points = {}, {}
-    for k in range(ks):
-        valid_points = []
-        for n in range(num_heats):
-            x, y, p = heat_loc[0, k, n]
-            if p >= prob_thre:
-                valid_points.append((x * scale, y * scale, p))
-        final_points[LINE_CLS[k]] = valid_points
-        if len(valid_points) >= 2:
-            line_paras[LINE_CLS[k]] = calculate_slope_intercept(valid_points[0][:2], valid_points[1][:2])
-    return line_paras, final_points
+    """heat_loc (1,K,2,3) rows [x, y, p] (numpy or torch) -> ({name: (k, b)}, {name: [(x,y,p)]}): per line class the peaks at or
+    above the threshold in image units, and the line through the first two of them."""
+    peaks = heat_loc.cpu().numpy() if hasattr(heat_loc, 'cpu') else np.asarray(heat_loc)
+    lines, points = {}, {}
+    for cls, rows in enumerate(peaks[0]):
+        kept = [(x * scale, y * scale, p) for x, y, p in rows if p >= prob_thre]
+        points[LINE_CLS[cls]] = kept
+        if len(kept) > 1:
+            lines[LINE_CLS[cls]] = calculate_slope_intercept(kept[0][:2], kept[1][:2])
+    return lines, points
 
 
 def line_eq_intersection(line1, line2) -> Optional[Tuple[float, float]]:
-    k1, b1 = line1
-    k2, b2 = line2
-    if abs(k1 - k2) > 1e-4:
-        x = (b2 - b1) / (k1 - k2)
-        return (x, k1 * x + b1)
-    return None
+    """Intersection of y = k x + b lines; None for (nearly) parallel ones (slopes within 1e-4, NaN slopes included)."""
+    (ka, ba), (kb, bb) = line1, line2
+    dk = ka - kb
+    if not abs(dk) > 1e-4:
+        return None
+    x = (bb - ba) / dk
+    return (x, ka * x + ba)
 
 
 def lines_to_keypoints(pred: Dict[str, Tuple[float, float]]) -> Dict[int, Tuple[float, float]]:

@@ -68,15 +68,7 @@ class CameraCreator:
             if name in self.pitch and not np.allclose(self.pitch[name], PITCH_POINTS[name], atol=1e-9):
                 raise ValueError(f'pitch point {name} differs from the built-in 105x68 m template')
         self.img_size = tuple(img_size)
-        self.lines_data = {}
-        if lines_file is not None:
-            assert os.path.exists(lines_file), f'{lines_file} does not exist'
-            with open(lines_file, 'rb') as f:
-                lines_data = pickle.load(f)
-            for img_name in lines_data.keys():
-                points = lines_to_keypoints(lines_data[img_name]['lines'][0])
-                if len(points) > 0:
-                    self.lines_data[img_name] = points
+        self.lines_data = self._line_keypoints(lines_file) if lines_file is not None else {}
         # defaults of the kwargs make_submit.py:45-50 passes
         self.conf_threshs = [0.5, 0.35, 0.2]
         self.max_rmse, self.max_rmse_rel = 55.0, 5.0
@@ -89,6 +81,16 @@ class CameraCreator:
         for key, value in kwargs.items():
             setattr(self, key, value)
         self.stat = {'n': 0, 'frames_4': 0, 'frames_4_6': 0, 'frames_bad_cam': 0}
+
+    @staticmethod
+    def _line_keypoints(lines_file) -> Dict[str, Dict[int, Tuple[float, float]]]:
+        """The line model's pickle (export_line_result.py:188-201) -> per image the keypoints its line pairs intersect in; images
+        without any are left out (prediction.py:105-124)."""
+        assert os.path.exists(lines_file), f'{lines_file} does not exist'
+        with open(lines_file, 'rb') as f:
+            per_image = pickle.load(f)
+        joined = ((name, lines_to_keypoints(rec['lines'][0])) for name, rec in per_image.items())
+        return {name: pts for name, pts in joined if pts}
 
     # ---- C ABI plumbing -------------------------------------------------------------------------------
     def _cfg(self):

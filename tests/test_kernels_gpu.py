@@ -483,3 +483,40 @@ def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
     n = lambda key: stats.get(key, {'ops': 0})['ops']
     assert n(k) + n(k48) >= 20 and n(k + ' split out') + n(k48 + ' split out') >= 150      # (fp32 outputs: module ends only)
     assert n(k) + n(k + ' split out') >= 144 and n(k48) + n(k48 + ' split out') >= 64
+
+
+def test_every_launch_of_the_bf16x3_engine_w32_270p(sncal, cuda):
+    """BASELINE config C2's shapes (HRNet-W32, 480x270): branch widths 32 / 64 / 128 / 256 all run as 64-channel blocks of the
+    64 x 12 x 32 tile (the 32-channel branch half padded), maps 68x120 / 34x60 / 17x30 / 9x15 (a 9-row branch inside 12-row tiles)."""
+    sd = _weights('hrnet_w32')
+    stats = verify_plan(sncal, cuda, 'hrnet_w32', sd, _frames(5, 270, 480, 19, cuda), 'bf16x3', tag='w32 270p bf16x3')
+    _report(stats, 'bf16x3_w32_270p')
+    k48 = 'conv_tt<bf16x3,k3,s1,12x32x64>'
+    n = lambda key: stats.get(key, {'ops': 0})['ops']
+    assert n(k48) + n(k48 + ' split out') >= 200, {k: v['ops'] for k, v in stats.items()}
+    assert any(k.startswith('conv<bf16x3,k3,s2') for k in stats) and any(k.startswith('conv<bf16x3,k1,s1') for k in stats)
+
+
+def test_every_launch_of_the_bf16x3_engine_w48_1080p_and_odd_sizes(sncal, cuda):
+    """C5's shapes (2 frames of 1920x1080) and a 270x500 input (68x125 / 34x63 / 17x32 / 9x16 maps, stem-interpolation head path)."""
+    sd = _weights('hrnet_w48')
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(2, 1080, 1920, 20, cuda), 'bf16x3', tag='w48 1080p bf16x3')
+    _report(stats, 'bf16x3_w48_1080p')
+    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and 'conv_tt<bf16x3,k3,s1,12x32x64> split out' in stats
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(5, 270, 500, 21, cuda), 'bf16x3', tag='w48 270x500 bf16x3')
+    _report(stats, 'bf16x3_w48_270x500')
+    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats
+
+
+def test_every_launch_of_the_bf16x3_engine_w18_and_line_net(sncal, cuda):
+    """W18 (18 / 36 / 72 / 144 channels: no two-team tiles, every convolution on the generic split-arithmetic kernel) and the line
+    network's head configuration."""
+    from oracle import hrnet_ref as hr
+    cfg = hr.load_config('hrnet_w18')
+    sd = hr.seeded_state_dict(cfg, 3, 4.0)
+    stats = verify_plan(sncal, cuda, 'hrnet_w18', sd, _frames(3, 135, 240, 22, cuda), 'bf16x3', tag='w18 135x240 bf16x3')
+    _report(stats, 'bf16x3_w18_135x240')
+    assert any(k.startswith('conv<bf16x3') for k in stats)
+    sd = _weights('line_hrnet_w48')
+    stats = verify_plan(sncal, cuda, 'line_hrnet_w48', sd, _frames(2, 540, 960, 23, cuda), 'bf16x3', tag='line w48 540p bf16x3')
+    _report(stats, 'bf16x3_line_w48_540p')

@@ -21,7 +21,7 @@ out = {k: {'mfma_util': round(u, 4), 'mfma_busy_cycles_per_launch': b, 'clocks_p
 json.dump(out, open(os.path.join(root, 'profiles', f'{tag}_pmc_mfma_util.json'), 'w'), indent=1)
 with open(os.path.join(root, 'profiles', f'{tag}_pmc_mfma_util.md'), 'w') as md:
     md.write(f'# Matrix-pipe utilisation per kernel from PMC counters ({tag})\n\n'
-             '`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -M --output-format csv -- python tools/dev_bench.py 64 bf16 1`\n'
+             '`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -M --output-format csv -- python tools/dev_bench.py 64 <engine> 1`\n'
              '(its own pass, tools/pmc_pass.sh).  utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of\n'
              'SIMD-cycles in which the matrix pipe holds an MFMA (includes MFMAs on padding pixels; a profiled pass runs at a lower clock than an\n'
              'unprofiled one, the ratio does not depend on it).\n\n'

@@ -2,12 +2,14 @@
 and a markdown table.  HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction of the guide)."""
 import json, sys, os
 d = sys.argv[1]; tag = sys.argv[2]; batch = sys.argv[3] if len(sys.argv) > 3 else '64'
-f = json.load(open(os.path.join(d, 'FETCH_SIZE', 'summary.json'))); w = json.load(open(os.path.join(d, 'WRITE_SIZE', 'summary.json')))
+f, w = {}, {}
+for dd in d.split(','):          # one directory per engine (tools/round_profile.sh: bf16x3 and bf16 passes), merged
+    f.update(json.load(open(os.path.join(dd, 'FETCH_SIZE', 'summary.json')))); w.update(json.load(open(os.path.join(dd, 'WRITE_SIZE', 'summary.json'))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {'note': f'per-launch HBM bytes from PMC at sub-batch {batch} (profiles/{tag}_pmc_hbm_traffic.md)'}
 rows = []
 def label(k):
-    return 'head_fused' if 'head32_kernel' in k or 'head_fused' in k else 'bblock48_fused' if 'bblock48_kernel' in k else k
+    return 'headx3_fused' if 'headx3' in k else 'head_fused' if 'head32_kernel' in k or 'head_fused' in k else 'bblock48_fused' if 'bblock48_kernel' in k else k
 f = {label(k): v for k, v in f.items()}; w = {label(k): v for k, v in w.items()}
 for k in f:
     if k not in w: continue
@@ -17,10 +19,10 @@ for k in f:
 json.dump(out, open(os.path.join(root, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
 with open(os.path.join(root, 'profiles', f'{tag}_pmc_hbm_traffic.md'), 'w') as md:
     md.write(f'# HBM traffic per launch from PMC counters ({tag})\n\n'
-             f'Two separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace -M --output-format csv -- python tools/dev_bench.py {batch} bf16 1`,\n'
+             f'Two separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace -M --output-format csv -- python tools/dev_bench.py {batch} <bf16x3 | bf16> 1`,\n'
              'same with `WRITE_SIZE`; tools/pmc_pass.sh).  FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of a\n'
              'wide coalesced read stream, so reads are doubled (MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated.\n\n'
              '| kernel | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM MB/launch |\n|---|---|---|---|\n')
-    for b, k, fk, wk in sorted(rows, reverse=True)[:12]:
+    for b, k, fk, wk in sorted(rows, reverse=True)[:24]:
         md.write(f'| `{k}` | {fk:.0f} | {wk:.0f} | {b / 1e6:.1f} |\n')
 print(open(os.path.join(root, 'profiles', f'{tag}_pmc_hbm_traffic.md')).read())

@@ -120,6 +120,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
+    bool use_conv_d2 = getenv("SNCAL_CONV_D2") ? atoi(getenv("SNCAL_CONV_D2")) != 0 : false;      // bf16: two teams, each double-buffered on 16-channel stages
     bool use_conv_t3 = getenv("SNCAL_CONV_T3") ? atoi(getenv("SNCAL_CONV_T3")) != 0 : false;      // bf16: three teams / 16-channel stages instead of two / 32
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
@@ -1263,7 +1264,8 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     sncal::launch_events() = armed;
     const bool cfg64 = x3 && n == 1 && net.layers[ops[0].conv].x3_blk == 64;   // bf16x3, 48-channel branch: tile 64 x 12 x 32
     const bool t3 = !fp8 && !x3 && net.use_conv_t3;                         // bf16: three teams, 16-channel stages
-    if (t3)
+    const bool d2 = !fp8 && !x3 && !t3 && net.use_conv_d2;                  // bf16: two teams, double-buffered 16-channel stages
+    if (t3 || d2)
         for (int i = 0; i < n; ++i) {
             const ConvLayer& L = net.layers[ops[i].conv];
             tp.m[i].w = L.d_w_t3;
@@ -1272,6 +1274,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         }
     if (fp8) key += 1 << 30;                                               // fp8 plans have their own stage counts
     if (t3) key += 1 << 29;
+    if (d2) key += 1 << 28;
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
@@ -1287,6 +1290,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
     if (t3) launch_conv_t3(tp, it->second.n_wgs, stream);
+    else if (d2) launch_conv_d2(tp, it->second.n_wgs, stream);
     else launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg64 ? 1 : 0);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
@@ -1319,7 +1323,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : t3 ? "conv_t3<bf16,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : t3 ? "conv_t3<bf16,k3,s1,8x32x96>" : d2 ? "conv_d2<bf16,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
     }
     return SNCAL_OK;
 }

@@ -88,6 +88,8 @@ struct ConvParams {
     int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA, bit2 skip weight DMA, bit3 skip halo DMA (results invalid)
     int epi_lds;                     // 1: transpose the output tile through LDS for 16-byte coalesced stores
     unsigned long long* trace;       // tuning aid (SNCAL_CONV_TRACE): 16 timestamps per workgroup, or null
+    void* out_twin;                  // x3_t only: split twin of the (dense, out_coff 0) output for the next two-team convolution, or null;
+                                     // out may then be null (nobody reads the fp32 form)
 };
 
 // pixel pitch (bytes) of the LDS halo tile that makes the B-fragment reads conflict-free
@@ -522,6 +524,20 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 }
             }
             if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            if constexpr (Elem<T>::X3) {
+                // [16 hi | 16 lo] bf16 per pixel and 16-channel group (conv_tt_body.inc): this lane's 4 channels are 8 + 8 bytes
+                if (p.out_twin) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+                    const float v[4] = {v0, v1, v2, v3};
+                    bf4 th, tl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { th[e] = (__bf16)v[e]; tl[e] = (__bf16)(v[e] - (float)th[e]); }
+                    char* const tw = reinterpret_cast<char*>(p.out_twin) + (pix * p.cout + (co & ~15)) * 4 + (co & 15) * 2;
+                    *reinterpret_cast<bf4*>(tw) = th;
+                    *reinterpret_cast<bf4*>(tw + 32) = tl;
+                }
+                if (!p.out) continue;
+            }
             if (p.out_f32 || GE == 4) {
                 float* dst = reinterpret_cast<float*>(p.out) + o;
                 if (co + 4 <= p.cout) *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);

@@ -128,6 +128,7 @@ struct sncal_hrnet {
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
     bool fp8 = false, fp8_calibrated = false, calibrating = false;
     bool x3_res_twin = true;     // bf16x3 engine: residuals of the two-team convolutions from the split twin (SNCAL_X3_RES_TWIN=0: from fp32)
+    bool x3_producer_twins = !(getenv("SNCAL_X3_SPLIT_PASS") && atoi(getenv("SNCAL_X3_SPLIT_PASS")) != 0);   // bf16x3: twins from the producers' epilogues, not from split_f32_kernel
     bool x3_generic = false;     // bf16x3 engine: generic convolutions on the x3_t variants (packed weights [4 hi | 4 lo] bf16 per k-group)
     bool x3 = false;                          // SNCAL_BF16X3: the fp32 engine with split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4
     unsigned fp8_stages = 0;                  // bit s: stage s selected (0 = all stages)
@@ -1133,7 +1134,23 @@ bool twin_written_by_producer(const sncal_hrnet& net, int t, int sb) {
         static const bool x3_split_always = getenv("SNCAL_X3_NO_TWIN_OUT") != nullptr;            // (dense outputs only)
         return !x3_split_always && po.out_coff == 0 && net.tensors[po.out].C == net.layers[po.conv].cout;
     }
+    if (net.x3 && net.x3_producer_twins && net.dtype == SNCAL_F32) {
+        // bf16x3: the generic split-arithmetic convolution and the fp32 fuse sum write the twin of a dense output in their epilogues
+        if (po.type == OP_CONV && net.x3_generic && !net.layers[po.conv].x3_on && po.out_coff == 0 && !po.out_f32 &&
+            net.tensors[po.out].C == net.layers[po.conv].cout && net.layers[po.conv].cout % 16 == 0) return true;
+        if (po.type == OP_UPADD && po.out_coff == 0 && net.tensors[po.out].C % 16 == 0) return true;
+    }
     return po.type == OP_CONV && net.layers[po.conv].fp8_on && tt_eligible(net, po, sb);
+}
+
+// bf16x3: the split twin a generic producer (convolution / fuse sum) writes for tensor t, or null; *skip_f32 = nobody reads the fp32 form
+void* producer_twin(const sncal_hrnet& net, int t, int sb, char* ws, bool* skip_f32) {
+    *skip_f32 = false;
+    if (!net.x3 || t < 0) return nullptr;
+    const Tensor& to = net.tensors[t];
+    if (to.twin < 0 || net.tensors[to.twin].first < 0 || !twin_written_by_producer(net, t, sb)) return nullptr;
+    *skip_f32 = !net.need_bf16[t];
+    return ws + net.tensors[to.twin].offset;
 }
 
 void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember& m) {
@@ -1336,6 +1353,11 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
     size_t best_lds = 0;
     const int rc = prepare_conv(net, op, sb, ws, p, bestv, best_lds);
     if (rc) return rc;
+    if (net.x3_generic) {        // bf16x3: the split twin for the two-team convolution that reads this output; fp32 only if somebody reads it
+        bool skip_f32 = false;
+        p.out_twin = producer_twin(net, op.out, sb, ws, &skip_f32);
+        if (p.out_twin && skip_f32) p.out = nullptr;
+    }
     // tuning aid: SNCAL_CONV_TRACE=<layer name> dumps per-workgroup phase timestamps of that layer's last launch
     static const char* trace_name = getenv("SNCAL_CONV_TRACE");
     unsigned long long* d_trace = nullptr; size_t n_trace = 0;
@@ -1829,6 +1851,11 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     }
                     p.out = ws + to.offset; p.N = sb; p.H = to.H; p.W = to.W; p.C = C0;
                     p.out_cstride = to.C; p.out_coff = op.out_coff; p.relu = op.relu ? 1 : 0;
+                    if (net->x3) {
+                        bool skip_f32 = false;
+                        p.out_twin = producer_twin(*net, op.out, sb, ws, &skip_f32);
+                        if (p.out_twin && skip_f32) p.out = nullptr;
+                    }
                     rc = launch_upsample_add(net->dtype, p, stream);
                     break;
                 }

@@ -18,6 +18,8 @@ struct UpsampleAddParams {
     int relu;
     unsigned cg_magic, w_magic;   // filled by the launcher: reciprocals of the odd parts of C/GE and W for the index decode
     unsigned cg_shift, w_shift;   // ... and their power-of-two parts (x / d = (x >> shift) / odd)
+    void* out_twin;          // fp32 path, bf16x3 engine: split twin ([16 hi | 16 lo] bf16 per 16-channel group, dense, out_coff 0) of the output, or null;
+                             // out may then be null
 };
 
 int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s);

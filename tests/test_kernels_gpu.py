@@ -275,7 +275,11 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             kern = 'conv_tt<fp8,k3,s1,8x32x96>' if op['fp8'] else ('conv_tt<bf16x3,k3,s1,12x32x64>' if op['cout'] % 96 else 'conv_tt<bf16x3,k3,s1,8x32x96>') if op.get('x3') else label
             name = f"{op['name']} {to['H']}x{to['W']} {op['cin']}->{op['cout']}" + ('+res' if op['res'] >= 0 else '')
             checked = False
-            if to['alive'] and not ((op['fp8'] or op.get('x3')) and not _bf16_written(net, ops, op)):
+            gen_twin = bool(op.get('x3g')) and _producer_twin(net, op, taps)
+            if gen_twin:
+                check(name + ' [split twin out]', _split_twin_value(T(op, to['twin'])), y, 1e-5 + 2.0 ** -16, abs_out + fp8_slack, stats, kern + ' split out')
+                checked = True
+            if to['alive'] and not ((op['fp8'] or op.get('x3') or gen_twin) and not _bf16_written(net, ops, op)):
                 got = nchw(T(op, op['out']))[:, op['out_coff']:op['out_coff'] + op['cout']]
                 if op['out_f32']:
                     check(name, got, y, 1e-5 if f32_engine else 2.0 ** -9, abs_out, stats, kern)     # fp32 logits of bf16 operands
@@ -310,8 +314,13 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 acc = acc + T(op, op['base']).to(torch.float32)
             if op['relu']:
                 acc = torch.relu(acc)
-            got = T(op, op['out']).to(torch.float32)[..., op['out_coff']:op['out_coff'] + C0]
-            check(f"fuse sum -> {to['H']}x{to['W']}x{C0} ({len(op['src'])} sources)", got, acc, rel_out, abs_out, stats, 'upsample_add')
+            nm = f"fuse sum -> {to['H']}x{to['W']}x{C0} ({len(op['src'])} sources)"
+            tw = dtype == 'bf16x3' and _producer_twin(net, op, taps)
+            if tw:          # bf16x3: the sum's split twin for the two-team convolution that reads it; the fp32 form only if somebody reads that
+                check(nm + ' [split twin out]', _split_twin_value(T(op, to['twin'])).permute(0, 2, 3, 1), acc, 1e-5 + 2.0 ** -16, abs_out, stats, 'upsample_add split out')
+            if not tw or _bf16_written(net, ops, op):
+                got = T(op, op['out']).to(torch.float32)[..., op['out_coff']:op['out_coff'] + C0]
+                check(nm, got, acc, rel_out, abs_out, stats, 'upsample_add')
         elif op['type'] == 'head':
             head_reference(net, op, T, W, by_idx, stats, cuda, exact=f32_engine)
         elif op['type'] == 'softmax':
@@ -324,6 +333,20 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             check('softmax head', got, ref, 1e-5, 1e-5, stats, 'softmax_nchw')
     stats['_case'] = dict(tag=tag, dtype=dtype, fp8_layers=fp8_layers, frames=int(B), input=list(x.shape[2:]))
     return stats
+
+
+def _split_twin_value(raw):
+    """(N,H,W,C) fp32-typed storage of a split twin -> (N,C,H,W) fp32: hi + lo."""
+    pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+    return (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
+
+
+def _producer_twin(net, op, taps):
+    """bf16x3: does this generic convolution / fuse sum write the split twin of its (dense) output?  (hrnet.cpp producer_twin)"""
+    to = net.plan_tensor(op['out'])
+    if to['twin'] < 0 or not net.plan_tensor(to['twin'])['alive'] or (op['idx'], to['twin']) not in taps:
+        return False
+    return op['out_coff'] == 0 and to['C'] % 16 == 0 and (op['type'] == 'upsample_add' or (op.get('x3g') and to['C'] == op['cout'] and not op['out_f32']))
 
 
 def _bf16_written(net, ops, op):

@@ -1207,7 +1207,9 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     }
     const int n_wgs = net.n_cus, nteams = teams_per_wg * n_wgs;
     std::vector<std::vector<TTItem>> per_team(nteams);
-    std::vector<uint32_t> load(nteams, 0);
+    std::vector<uint32_t> load(nteams, 0), cost(nteams, 0);
+    // balancing cost of an item in quarter stages: its stages + a tile-boundary term (epilogue + set-up + first landing)
+    static const int boundary_q = getenv("SNCAL_TT_BOUNDARY") ? atoi(getenv("SNCAL_TT_BOUNDARY")) : 0;
     std::vector<std::vector<int>> xcd_teams(8);
     for (int b = 0; b < n_wgs; ++b)
         for (int t = 0; t < teams_per_wg; ++t) xcd_teams[b % 8].push_back(teams_per_wg * b + t);
@@ -1225,7 +1227,7 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
             size_t best = cursor[x] % tl.size();
             for (size_t k = 0; k < tl.size(); ++k) {      // least loaded, scanning from the rotating cursor
                 const size_t cand = (cursor[x] + k) % tl.size();
-                if (load[tl[cand]] < load[tl[best]]) best = cand;
+                if (cost[tl[cand]] < cost[tl[best]]) best = cand;
             }
             cursor[x] = best + 1;
             TTItem it;
@@ -1234,6 +1236,7 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
             it.col0 = (int32_t)(tile % tiles_x) * TT_TW; it.row0 = (int32_t)(tile / tiles_x) * tile_h; it.pad_ = 0;
             per_team[tl[best]].push_back(it);
             load[tl[best]] += (uint32_t)m.chunks;
+            cost[tl[best]] += (uint32_t)(4 * m.chunks + boundary_q);
         }
     }
     // (Interleaving the members' items inside a team, so that the memory-heavy 96-channel tiles do not all run at the tail of

@@ -498,6 +498,122 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
             return;
         }
     }
+    // ---- epilogue F (fp32 outputs: the exact-fp32 and the bf16x3 engine): the same transpose through LDS, every lane then handles 4
+    // consecutive channels of one pixel -- residual load and output store are 16 bytes per lane and MI * 64 contiguous bytes per pixel
+    // (the direct epilogue below writes 64-byte pieces per pixel and instruction; with it the 1x1 convolutions of layer1, 2 GB in and
+    // 2 GB out per launch, ran at 3 TB/s with or without their MFMA phase).  Same arithmetic, same bits.  BRANCH-FREE like conv_tt's:
+    // loads and stores go through buffer descriptors of one image, an item outside the image / beyond Cout carries an out-of-range
+    // offset (loads return zeros, stores are dropped), a missing residual / output / twin is a zero-sized descriptor.  (With `if (ok)`
+    // around every load hipcc branched around each one and spilled the accumulators: 164-392 bytes of scratch per lane.)
+    if constexpr (GE == 4) {
+        if (p.epi_lds) {
+            constexpr int CO = MI * 16, PITCH = CO + 4, GROUPS = CO / 4, EITERS = MI;      // 16 pixels x GROUPS items = 64 * MI
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            asm volatile("s_barrier" ::: "memory");                        // all waves are done with the staging buffers
+            constexpr bool PRE_ALL = NI * MI <= 8;
+            constexpr int JBH = conv_epi_frags(KS, NI, MI, G);                   // fragments per wave the host reserved staging for
+            constexpr int JB = PRE_ALL ? JBH : 1;                                // big register tiles: one fragment at a time, the next one's residual in flight
+            float* stg = reinterpret_cast<float*>(smem) + wave * (JBH * 16 * PITCH);
+            int lane_l = lane;               // laundered: hipcc would hoist the lane-only item arithmetic above the main loop
+            asm volatile("" : "+v"(lane_l));
+            const int img_b = p.Hout * p.Wout * p.out_cstride * 4;              // bytes of one image of the output tensor (< 2 GB)
+            char* const in_c = const_cast<char*>(reinterpret_cast<const char*>(p.in));
+            const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+                p.res ? const_cast<char*>(reinterpret_cast<const char*>(p.res)) + img_out * 4 : in_c, 0, p.res ? img_b : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+                p.out ? reinterpret_cast<char*>(p.out) + img_out * 4 : in_c, 0, p.out ? img_b : 0, 0x00020000);
+            const bool has_twin = Elem<T>::X3 && p.out_twin != nullptr;         // dense output (out_coff 0, stride = cout): same image size
+            const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(
+                has_twin ? reinterpret_cast<char*>(p.out_twin) + img_out * 4 : in_c, 0, has_twin ? img_b : 0, 0x00020000);
+            // item offsets + residuals: for ALL fragments up front when the registers allow (the latency is paid once), else one
+            // fragment ahead
+            constexpr int NR = PRE_ALL ? NI : 2 * JB;
+            unsigned off[NR][EITERS];
+            u32x4 rr[NR][EITERS];
+            auto fetch = [&](int j, int slot) __attribute__((always_inline)) {
+                const int f = wave * NI + j;
+                const int fr = f >> TWF_LOG2, fx = f & (TWF - 1);
+                const int oy = oy00 + fr;
+#pragma unroll
+                for (int it = 0; it < EITERS; ++it) {
+                    const int id = it * 64 + lane_l;
+                    const int px = id / GROUPS, grp = id - px * GROUPS;
+                    const int ox = ox0 + fx * 16 + px;
+                    const int co = nb * CO + grp * 4;
+                    const bool ok = (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
+                    off[slot][it] = ok ? (unsigned)(((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) * 4) : 0x80000000u;
+                    rr[slot][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[slot][it], 0, 0);
+                }
+            };
+            if constexpr (PRE_ALL) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fetch(j, j);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) fetch(jj, jj);
+            }
+#pragma unroll
+            for (int j0 = 0; j0 < NI; j0 += JB) {
+                const int base = PRE_ALL ? j0 : ((j0 / JB) & 1) * JB;              // slots of this block
+                if constexpr (!PRE_ALL) {
+                    if (j0 + JB < NI) {
+#pragma unroll
+                        for (int jj = 0; jj < JB; ++jj) fetch(j0 + JB + jj, (((j0 / JB) + 1) & 1) * JB + jj);      // the next block's, under this block's work
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int j = j0 + jj;
+                        *reinterpret_cast<float4*>(stg + (jj * 16 + ln) * PITCH + mi * 16 + g * 4) =
+                            make_float4(acc[mi][j][0], acc[mi][j][1], acc[mi][j][2], acc[mi][j][3]);
+                    }
+                // wave-local hand-off: LDS operations of one wave complete in order
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+#pragma unroll
+                    for (int it = 0; it < EITERS; ++it) {
+                        const unsigned o = off[base + jj][it];
+                        const int id = it * 64 + lane_l;
+                        const int px = id / GROUPS, grp = id - px * GROUPS;
+                        const float4 a4 = *reinterpret_cast<const float4*>(stg + (jj * 16 + px) * PITCH + grp * 4);
+                        const u32x4 r = rr[base + jj][it];
+                        float v[4] = {a4.x + __uint_as_float(r[0]), a4.y + __uint_as_float(r[1]), a4.z + __uint_as_float(r[2]), a4.w + __uint_as_float(r[3])};
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        u32x4 ov = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        if constexpr (Elem<T>::X3) {
+                            if (has_twin) {        // wave-uniform: [16 hi | 16 lo] bf16 per pixel and 16-channel group, this lane's 4 channels are 8 + 8 bytes
+                                typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+                                bf4 th, tl;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { th[e] = (__bf16)v[e]; tl[e] = (__bf16)(v[e] - (float)th[e]); }
+                                const unsigned c16 = (unsigned)(grp * 4) & 15u;          // (nb * CO is a multiple of 16)
+                                const unsigned toff = o == 0x80000000u ? o : o - c16 * 2;  // byte offset of the group's hi half + this lane's 8 bytes
+                                u32x2 t0 = __builtin_bit_cast(u32x2, th), t1 = __builtin_bit_cast(u32x2, tl);
+                                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ov));
+                                __builtin_amdgcn_raw_buffer_store_b64(t0, rs_tw, toff, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b64(t1, rs_tw, toff, 32, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(ov, rs_out, o, 0, 0);
+                                asm volatile("s_nop 3" :: "v"(t0), "v"(t1), "v"(ov) : "memory");     // store data stays untouched behind the stores
+                                continue;
+                            }
+                        }
+                        asm volatile("" : "+v"(ov));
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, rs_out, o, 0, 0);
+                        asm volatile("s_nop 1" :: "v"(ov) : "memory");
+                    }
+                }
+                if constexpr (!PRE_ALL) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+    }
     // epilogue: (+ residual) (ReLU) -> store 4 consecutive channels per lane
 #pragma unroll
     for (int j = 0; j < NI; ++j) {

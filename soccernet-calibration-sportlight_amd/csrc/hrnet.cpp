@@ -1072,7 +1072,10 @@ int prepare_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, ConvParams& p
         static const int epi = getenv("SNCAL_EPI_LDS") ? atoi(getenv("SNCAL_EPI_LDS")) : 1;
         const int wgs = conv_resident_wgs(L.k, bestv->ni, L.mi, L.g);
         const size_t need = (size_t)4 * conv_epi_frags(L.k, bestv->ni, L.mi, L.g) * 16 * (L.mi * 16 + 4) * 4;
-        const bool shape_ok = net.dtype == SNCAL_BF16 && !op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0;
+        // bf16: whole 8-channel groups; fp32 / bf16x3 engines (epilogue F): whole 4-channel groups (SNCAL_EPI_F32=0: the direct epilogue)
+        static const int epi32 = getenv("SNCAL_EPI_F32") ? atoi(getenv("SNCAL_EPI_F32")) : 1;
+        const bool shape_ok = net.dtype == SNCAL_BF16 ? (!op.out_f32 && L.cout % 8 == 0 && to.C % 8 == 0 && op.out_coff % 8 == 0)
+                                                     : (epi32 && L.cout % 4 == 0 && to.C % 4 == 0 && op.out_coff % 4 == 0);
         const size_t now_per_cu = std::min<size_t>(wgs, (160 * 1024) / best_lds);
         const bool fits = need <= best_lds || need <= (160 * 1024) / now_per_cu || need <= 52 * 1024;
         p.epi_lds = (epi && shape_ok && fits) ? 1 : 0;

@@ -87,11 +87,12 @@ def test_line_net_matches_reference(sncal, cuda, gold_dir, name, cfgn, dtype, to
         assert np.array_equal(dec[..., :2], g['decode'][..., :2])
 
 
-def test_batch_and_subbatch_consistency(sncal, cuda):
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+def test_batch_and_subbatch_consistency(sncal, cuda, dtype):
     """Frames are independent: a batch of 11 (sub-batches 8 + 3) equals per-frame results bit-for-bit."""
     cfg = hr.load_config('hrnet_w18')
     sd = hr.seeded_state_dict(cfg, 9, 4.0)
-    net = sncal.HRNetHeatmap('hrnet_w18', dtype='bf16', device=cuda)
+    net = sncal.HRNetHeatmap('hrnet_w18', dtype=dtype, device=cuda)
     net.load_state_dict(sd)
     x = hr.seeded_input(11, 64, 96, 10).to(cuda)
     heat, kp = net.forward(x, want_heat=True, decode_size=(540, 960))
@@ -248,13 +249,14 @@ def test_two_team_conv_kernel_matches_the_generic_kernel(sncal, cuda, monkeypatc
     assert float((kps[0][..., :2] == kps[1][..., :2]).all(-1).float().mean()) >= 0.9
 
 
-def test_frames_are_independent_of_batch_size_and_position(sncal, cuda):
-    """Size-independent property at the bench configuration (W48, 960x540, bf16): a frame's keypoints and heatmap do not
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+def test_frames_are_independent_of_batch_size_and_position(sncal, cuda, dtype):
+    """Size-independent property at the bench configuration (W48, 960x540, both fast engines): a frame's keypoints and heatmap do not
     depend on the batch it travels in -- different batch sizes pick different tile shapes, grid orders and grouped
     launches, and a 67-frame batch crosses the 64-frame sub-batch boundary -- because every output element is accumulated
     in a fixed order."""
     cfg = hr.load_config('hrnet_w48')
-    net = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16', device=cuda)
+    net = sncal.HRNetHeatmap('hrnet_w48', dtype=dtype, device=cuda)
     net.load_state_dict(hr.seeded_state_dict(cfg, 1, 1.5))
     x = torch.rand((67, 3, 540, 960), device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
     _, k_all = net.forward(x, want_heat=False, decode_size=(540, 960))

@@ -1,0 +1,57 @@
+"""Parity of the fast engines against the exact-fp32 engine on MANY frames of the deep-path workload (bench.py's `parity` object is the
+same comparison on the 64 benchmarked frames): keypoint indices and the solved cameras' reprojection error.
+usage (GPU box): python tools/parity_large.py [frames=512] [row_gain=0.1] -> gpurun_out/parity_large_<frames>.json"""
+import json, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sncal_amd
+import bench
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+row_gain = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+dev = torch.device('cuda:0')
+sd = sncal_amd.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True, row_gain=row_gain)
+cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **bench.SOLVER_KW)
+res = {}
+kps = {}
+for dtype in ('fp32', 'bf16x3', 'bf16'):
+    net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
+    net.load_state_dict(sd)
+    out = []
+    for lo in range(0, N, 64):
+        n = min(64, N - lo)
+        frames, _ = sncal_amd.synth.stamped_frames(n, seed=5000 + lo, size=(540, 960))
+        _, kp = net.forward(torch.from_numpy(frames).to(dev), want_heat=False, decode_size=(540, 960))
+        out.append(kp.clone())
+    kps[dtype] = torch.cat(out, 0)
+    del net
+recs = {d: cc.records(cc.solve_device(kps[d])) for d in kps}
+for d in ('bf16x3', 'bf16'):
+    res[d] = bench.parity_of(kps['fp32'].cpu().numpy(), recs['fp32'], kps[d].cpu().numpy(), recs[d], 'exact-fp32 engine of this build')
+    res[d]['row_gain'] = row_gain
+    print(d, {k: res[d][k] for k in ('frames', 'usable_keypoints', 'moved_usable_keypoints', 'index_agreement', 'index_agreement_all_rows', 'cameras_both',
+                                     'frames_rmse_rel_delta_le_1e-4', 'rmse_rel_delta_max')})
+# the moved keypoints of bf16x3: how close was the decision in the exact-fp32 heatmap?  (top-1 minus the value at the cell bf16x3 chose, log-probability)
+k32, k3 = kps['fp32'].cpu().numpy(), kps['bf16x3'].cpu().numpy()
+moved = np.argwhere((k32[..., 2] >= 0.2) & ((k32[..., :2] != k3[..., :2]).any(-1)))
+net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='fp32', device=dev)
+net.load_state_dict(sd)
+gaps = []
+for f, k in moved[:32]:
+    lo = int(f) // 64 * 64
+    n = min(64, N - lo)
+    frames, _ = sncal_amd.synth.stamped_frames(n, seed=5000 + lo, size=(540, 960))
+    heat, _ = net.forward(torch.from_numpy(frames[int(f) - lo:int(f) - lo + 1]).to(dev), want_heat=True, decode_size=(540, 960))
+    h = heat[0, int(k)].cpu().numpy()                      # (270, 480) log-probabilities
+    sx, sy = 960 / h.shape[1], 540 / h.shape[0]
+    c32 = (int(round(k32[f, k, 1] / sy)), int(round(k32[f, k, 0] / sx)))
+    c3 = (int(round(k3[f, k, 1] / sy)), int(round(k3[f, k, 0] / sx)))
+    c32 = (min(c32[0], h.shape[0] - 1), min(c32[1], h.shape[1] - 1)); c3 = (min(c3[0], h.shape[0] - 1), min(c3[1], h.shape[1] - 1))
+    gaps.append(dict(frame=int(f), keypoint=int(k), fp32_cell=c32, bf16x3_cell=c3, fp32_logp_at_fp32_cell=float(h[c32]), fp32_logp_at_bf16x3_cell=float(h[c3]),
+                     gap=float(h.max() - h[c3]), conf=float(k32[f, k, 2])))
+    print('moved', gaps[-1])
+res['bf16x3']['moved_keypoints_fp32_gap'] = gaps
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'parity_large_{N}_rowgain{row_gain}.json'), 'w'), indent=1)

@@ -744,7 +744,8 @@ void conv_group_launch(const ConvGroupParams& gp, dim3 grid, size_t lds, hipStre
 // only: compile time
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
 constexpr ConvGroupLaunchFn conv_group_fn() {
-    if constexpr (Elem<T>::GE == 8 && STRIDE == 1 && ((KS == 3 && MI == 6) || (KS == 1 && G == 8 && (MI == 3 || MI == 6))))
+    if constexpr ((Elem<T>::GE == 8 && STRIDE == 1 && ((KS == 3 && MI == 6) || (KS == 1 && G == 8 && (MI == 3 || MI == 6)))) ||
+                  (Elem<T>::X3 && STRIDE == 1 && KS == 1 && G == 8 && (MI == 3 || MI == 6)))      // bf16x3: the fuse-up 1x1 convs
         return &conv_group_launch<T, KS, STRIDE, NI, MI, G>;
     else return nullptr;
 }

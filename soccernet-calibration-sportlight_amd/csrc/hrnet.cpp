@@ -1422,6 +1422,11 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         size_t l = 0;
         const int rc = prepare_conv(net, ops[i], sb, ws, mp[i], v, l);
         if (rc) return rc;
+        if (net.x3_generic) {
+            bool skip_f32 = false;
+            mp[i].out_twin = producer_twin(net, ops[i].out, sb, ws, &skip_f32);
+            if (mp[i].out_twin && skip_f32) mp[i].out = nullptr;
+        }
         if (i == 0) v0 = v;
         if (v != v0 || !v->launch_group) return SNCAL_OK;
         lds = std::max(lds, l);

@@ -300,20 +300,24 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
         const int ox = ox0 + fx * 16 + px;
         const int co = nb * EPI_CO + grp * 8;
         const bool ok = (id < EPI_ITEMS) & (oy < p.Hout) & (ox < p.Wout) & (co < p.cout);
-        return ok ? (unsigned)((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) : 0xFFFFFFFFu;
+        return ok ? (unsigned)(((oy * p.Wout + ox) * p.out_cstride + p.out_coff + co) * 2) : 0x80000000u;      // bytes inside the image; out of range = nothing
     };
+    // branch-free residual loads / output stores of epilogue A: per-image buffer descriptors, a missing residual is a zero-sized one
+    // (loads return zeros), an item outside the image carries an out-of-range offset (epilogue F has the measurements)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int img_b16 = p.Hout * p.Wout * p.out_cstride * 2;
+    const __amdgpu_buffer_rsrc_t rs_res16 = __builtin_amdgcn_make_buffer_rsrc(
+        p.res ? const_cast<char*>(reinterpret_cast<const char*>(p.res)) + img_out * 2 : const_cast<char*>(reinterpret_cast<const char*>(p.in)), 0,
+        p.res ? img_b16 : 0, 0x00020000);
     if constexpr (GE == 8 && RES_PF) {
         if (epi_a) {
-            const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int it = 0; it < EPI_ITERS; ++it) {
                     const unsigned o = epi_offset(j, it);
                     eoff[j][it] = o;
-                    bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (p.res && o != 0xFFFFFFFFu) r = *reinterpret_cast<const bf16x8*>(res_img + o);
-                    res_pf[j][it] = r;
+                    res_pf[j][it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_res16, o, 0, 0));
                 }
         }
     }
@@ -431,8 +435,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
             constexpr int JB = conv_epi_frags(KS, NI, MI, G);                              // fragments staged at a time
             float* stg = reinterpret_cast<float*>(smem) + wave * (JB * 16 * PITCH);
             constexpr int GROUPS = EPI_GROUPS, EITERS = EPI_ITERS;
-            const __bf16* const res_img = reinterpret_cast<const __bf16*>(p.res) + img_out;
-            __bf16* const out_img = reinterpret_cast<__bf16*>(p.out) + img_out;
+            const __amdgpu_buffer_rsrc_t rs_out16 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + img_out * 2, 0, img_b16, 0x00020000);
             // item offsets: kept from the prologue when the residual was prefetched; otherwise computed here and the
             // residual is requested for ALL fragments first -- the fragment registers of the main loop are dead --
             // so its latency is paid once, not once per staged block
@@ -446,9 +449,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                         off[j][it] = eoff[j][it];
                     } else {
                         off[j][it] = epi_offset(j, it);
-                        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (p.res && off[j][it] != 0xFFFFFFFFu) r = *reinterpret_cast<const bf16x8*>(res_img + off[j][it]);
-                        rr[j][it] = r;
+                        rr[j][it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_res16, off[j][it], 0, 0));
                     }
                 }
 #pragma unroll
@@ -467,10 +468,10 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 for (int jj = 0; jj < JB; ++jj) {
 #pragma unroll
                     for (int it = 0; it < EITERS; ++it) {
-                        if (off[j0 + jj][it] != 0xFFFFFFFFu) {
+                        {
                             const int id = it * 64 + lane;
                             const int px = id / GROUPS, grp = id - px * GROUPS;
-                            const float* sp = stg + (jj * 16 + px) * PITCH + grp * 8;
+                            const float* sp = stg + (jj * 16 + (EPI_ITEMS % 64 ? min(px, 15) : px)) * PITCH + grp * 8;      // (lanes beyond the last item store nothing)
                             const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
                             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                             if (p.res) {
@@ -489,7 +490,10 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                                 const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                                 q = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, q), zero));
                             }
-                            *reinterpret_cast<bf16x8*>(out_img + off[j0 + jj][it]) = q;
+                            u32x4_t qd = __builtin_bit_cast(u32x4_t, q);
+                            asm volatile("" : "+v"(qd));
+                            __builtin_amdgcn_raw_buffer_store_b128(qd, rs_out16, off[j0 + jj][it], 0, 0);
+                            asm volatile("s_nop 1" :: "v"(qd) : "memory");     // store data stays untouched behind the store
                         }
                     }
                 }

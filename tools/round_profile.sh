@@ -11,6 +11,7 @@ python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c
 python bench.py --dtype fp8 --no-cpu-baseline > $O/bench_c3_fp8.json 2> $O/bench_c3_fp8.err
 python bench.py --dtype fp8 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5_fp8.err
 python bench.py --dtype bf16 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
+python bench.py --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16x3.json 2> $O/bench_c5_bf16x3.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

@@ -541,7 +541,8 @@ def main():
             pass
         peak = PEAK_TFLOPS['fp8' if 'fp8' in dom['kernel'] else 'bf16' if args.dtype == 'fp8' else args.dtype]
         flop_frame = (FLOP_KEYPOINT_NET if args.size == '540p' else FLOP_KEYPOINT_NET_1080P) + (FLOP_LINE_NET if c4 else 0)
-        wl = (f'C5: HRNet-W48 1920x1080, batch {B} per GPU, {args.dtype}{' (fp8 layers: ' + args.fp8_layers + ')' if args.dtype == 'fp8' else ''}, heatmap 540x960 + decode + batched camera solve (iterative_voter)'
+        dtype_label = args.dtype + (f' (fp8 layers: {args.fp8_layers})' if args.dtype == 'fp8' else '')
+        wl = (f'C5: HRNet-W48 1920x1080, batch {B} per GPU, {dtype_label}, heatmap 540x960 + decode + batched camera solve (iterative_voter)'
               if args.size == '1080p' else 'C4: HRNet-W48 keypoint net + HRNet-W48 line net, 960x540, batch 64 per GPU, decodes + device line join + batched camera solve (iterative_voter)'
               if c4 else 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter) on the decoded keypoints')
         out = {

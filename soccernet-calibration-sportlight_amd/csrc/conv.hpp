@@ -385,9 +385,9 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 // A = [w_hi | w_lo] as packed (element e of A meets element e of B): B = [x_lo | x_hi] gives the cross terms
                 // w_hi.x_lo + w_lo.x_hi, B = [x_hi | 0] the main term -- small terms first.
                 // (The main term as v_mfma_f32_16x16x16_bf16 on the low halves was built first: same issue time, two registers fewer per
-                // B fragment -- and WRONG on gfx950 as hipcc 7.2 schedules it: it pairs the K = 16 instruction back to back with the
-                // K = 32 one whose vDst it reads as SrcC, and gives it a vDst that overlaps its SrcC by half (v[68:71] <- v[70:73]);
-                // elements 0 and 1 of such tiles came out wrong.  Found by the per-kernel test.)
+                // B fragment -- and WRONG on gfx950 as hipcc 7.2 schedules it: back to back behind the K = 32 instruction whose vDst it
+                // reads as SrcC, with no wait states; accumulator registers 0 and 1 of such tiles came out wrong.  Found by the per-kernel
+                // test, isolated by tools/dev/mfma_pair_probe.hip.)
                 bf16x8 bx[NI], bm[NI];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {

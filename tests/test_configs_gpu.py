@@ -36,6 +36,14 @@ def test_c2_w32_480x270_batch32_decode(sncal, cuda):
     # typical |logp| ~ 10 (ulp 0.06; measured 0.066), isolated worst case below 1 (measured 0.53)
     db = np.abs(hb[:2].cpu().numpy() - ref)
     assert db.mean() < 0.12 and db.max() < 1.0
+    # the fp32-class engine (every branch width of W32 on the 64 x 12 x 32 two-team tile, stem-interpolation head on the generic
+    # split-arithmetic kernels): oracle indices, log-probabilities to 1e-3
+    net3 = sncal.HRNetHeatmap('hrnet_w32', dtype='bf16x3', device=cuda)
+    net3.load_state_dict(sd)
+    h3, k3 = net3.forward(x.to(cuda), want_heat=True, decode_size=(540, 960))
+    assert np.abs(h3[:2].cpu().numpy() - ref).max() <= 1e-3
+    assert np.array_equal(k3[:2].cpu().numpy()[..., :2], od.keypoint_decode(ref, (540, 960))[..., :2])
+    assert np.array_equal(k3.cpu().numpy()[..., :2], kp.cpu().numpy()[..., :2])          # all 32 frames: the fp32 engine's indices
 
 
 def test_c4_keypoint_and_line_networks_joined(sncal, cuda):
@@ -118,6 +126,13 @@ def test_c5_w48_1080p_flagship(sncal, cuda):
     assert torch.equal(k16, k16b)                                  # fused decode at 540x960
     d = np.abs(h16[:1].cpu().numpy() - ref)
     assert d.mean() < 0.12 and d.max() < 1.0, (d.mean(), d.max())
+    del h16, net16
+    torch.cuda.empty_cache()
+    net3 = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16x3', device=cuda)          # the fp32-class engine at C5's shapes: oracle indices
+    net3.load_state_dict(sd)
+    h3, k3 = net3.forward(x[:1].to(cuda), want_heat=True, decode_size=(1080, 1920))
+    assert np.abs(h3.cpu().numpy() - ref).max() <= 1e-3
+    assert np.array_equal(k3.cpu().numpy()[..., :2], od.keypoint_decode(ref, (1080, 1920))[..., :2])
 
 
 def test_pipeline_overlapped_solve_matches_direct(sncal, cuda):

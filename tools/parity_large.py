@@ -53,5 +53,23 @@ for f, k in moved[:32]:
                      gap=float(h.max() - h[c3]), conf=float(k32[f, k, 2])))
     print('moved', gaps[-1])
 res['bf16x3']['moved_keypoints_fp32_gap'] = gaps
+# frames whose cameras differ although no usable index moved: does a confidence cross one of the solver's thresholds?
+r32, r3 = recs['fp32'], recs['bf16x3']
+odd = []
+for i in range(N):
+    if r32[i].status == 0 or r3[i].status == 0 or r32[i].rmse <= 0:
+        continue
+    if abs(r3[i].rmse - r32[i].rmse) / r32[i].rmse <= 1e-4:
+        continue
+    usable = k32[i, :, 2] >= 0.2
+    if ((k32[i, :, :2] != k3[i, :, :2]).any(-1) & usable).any():
+        continue
+    cross = [(int(k), float(k32[i, k, 2]), float(k3[i, k, 2])) for k in range(k32.shape[1])
+             for th in (0.5, 0.35, 0.2) if (k32[i, k, 2] >= th) != (k3[i, k, 2] >= th)]
+    other = [(int(k), float(k32[i, k, 0]), float(k32[i, k, 1]), float(k3[i, k, 0]), float(k3[i, k, 1])) for k in range(k32.shape[1])
+             if (k32[i, k, :2] != k3[i, k, :2]).any()]
+    odd.append(dict(frame=i, rmse_fp32=float(r32[i].rmse), rmse_bf16x3=float(r3[i].rmse), threshold_crossings=cross, moved_unusable_rows=other[:4]))
+    print('camera differs, no usable index moved:', odd[-1])
+res['bf16x3']['cameras_differ_without_moved_usable_index'] = odd
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'parity_large_{N}_rowgain{row_gain}.json'), 'w'), indent=1)

@@ -615,7 +615,10 @@ int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
             for (int s = 0; s < 9; ++s)
                 for (int mb = 0; mb < MBk; ++mb)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int co = nb * L.x3_blk + mb * 32 + (lane & 31);
+                        // MFMA row r = lane & 31 computes channel x3_row_channel(r) of its block: quads 2 p, 2 p + 1 of a lane's accumulator
+                        // registers are then 8 consecutive channels (conv_tt_body.inc x3_quad_channel, the twin-only epilogue)
+                        const int r = lane & 31, rq = r >> 3, rh = (r >> 2) & 1, ri = r & 3;
+                        const int co = nb * L.x3_blk + mb * 32 + 16 * (rq >> 1) + 8 * rh + 4 * (rq & 1) + ri;
                         if (co >= L.cout) continue;
                         uint16_t* hi = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 0) * MBk + mb) * 64 + lane) * 8;
                         uint16_t* lo = host.data() + ((((((size_t)nb * chunks + c) * 9 + s) * 2 + 1) * MBk + mb) * 64 + lane) * 8;

@@ -1310,10 +1310,14 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     tp.items = it->second.items; tp.team_first = it->second.first; tp.team_stages = it->second.stages;
     // tuning aid: SNCAL_TT_TRACE=<file> dumps the per-team phase timestamps of the LAST launch with 3 members
+    // (SNCAL_TT_TRACE_CFG64=1: of the last launch of the 64-channel tile instead)
     static const char* trace_file = getenv("SNCAL_TT_TRACE");
+    static const bool trace_cfg64 = getenv("SNCAL_TT_TRACE_CFG64") && atoi(getenv("SNCAL_TT_TRACE_CFG64")) != 0;
+    static const int trace_nth = getenv("SNCAL_TT_TRACE_NTH") ? atoi(getenv("SNCAL_TT_TRACE_NTH")) : -1;      // only the n-th such launch of the process
+    static int trace_seen = 0;
     unsigned long long* d_trace = nullptr;
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
-    if (trace_file && n == 3 && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
+    if (trace_file && (trace_cfg64 ? cfg64 : n == 3) && (trace_nth < 0 || trace_seen++ == trace_nth) && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
     if (t3) launch_conv_t3(tp, it->second.n_wgs, stream);
     else if (d2) launch_conv_d2(tp, it->second.n_wgs, stream);

@@ -1,0 +1,371 @@
+// Fused BasicBlock of the 48-channel full-resolution branch in SPLIT arithmetic (the fp32-class engine `bf16x3`):
+//     out = ReLU( BN2(conv2( ReLU(BN1(conv1(x))) )) + x )          /root/reference/src/models/hrnet/hrnet.py:42-58
+// in ONE persistent kernel, every product as w_hi.x_hi + w_hi.x_lo + w_lo.x_hi on the 16-bit matrix pipe with fp32 accumulation.
+//
+// Why (round 4).  As two launches of the two-team kernel (conv_tt, 64-channel x 12-row tile) the block cost 2 x 357 us per 64 frames at
+// 0.27 of the split-arithmetic roof: 48 channels ran as a padded 64-row MFMA block (25 % zero rows), every tile of three 16-channel
+// stages paid a tile boundary as long as its multiplies (phase traces: epilogue 10k clk, 24k with the residual reads; the x halo of every
+// stage fetched from HBM by a team that cannot load while it multiplies), and the pair moved 5.5 tensor passes through HBM (x halo, mid
+// out, mid halo, residual, out) where 2.3 are needed.  Here:
+//   * v_mfma_f32_16x16x32: three 16-row blocks = 48 output channels exactly, no padded rows;
+//   * the split form costs 1.5 MFMAs per (16 x 16 outputs, 16 channels of one tap) instead of 2: the two CROSS terms of a unit share
+//     one K = 32 instruction (A = [w_hi | w_lo] against B = [x_lo | x_hi]) and the MAIN terms of two units share another
+//     (A = [w_hi(u0) | w_hi(u1)], B = [x_hi(u0) | x_hi(u1)]); units are paired so that the second unit's pixels sit at one of three
+//     constant distances from the first's (bblockx3.hpp);
+//   * x halo (20 x 18 pixels) and the mid tile (18 x 16) live in LDS as separate hi and lo PLANES of 96 bytes per pixel: the K octets
+//     of a B fragment are then adjacent 16-byte slots at a pixel pitch of 6 slots, which is conflict-free for ds_read_b128's lane groups
+//     ({ln 0-3,12-15 | octet 0} + {ln 4-11 | octet 1} hit the even / the odd slots) without padding; the twin's [16 hi | 16 lo] groups
+//     are de-interleaved by the DMA's per-lane source address;
+//   * weights (2 x 84 KB, more than the LDS left beside the tiles) stream through a 4-slot ring of 6 KB pair-steps, x halo and weights
+//     are requested by a NINTH wave that does nothing else, so no multiplying wave ever issues a DMA or waits on vmcnt: its hand-offs
+//     are counters in LDS (w_ready / w_done per step, x_ready / x_free per tile), the eight multiplying waves meet only at the mid tile;
+//   * the residual is the centre of the x halo (registers, read before the halo region is handed back), the next tile's halo lands
+//     under conv2, the output is stored straight from the accumulators as the split twin the next block reads and / or as fp32.
+// Arithmetic: hi = rne16(v), lo = rne16(v - hi); mid is split exactly like a tensor that conv_tt would have written, so the block
+// equals conv1 -> twin -> conv2 of the two-kernel path up to the summation order inside the matrix unit.
+#include "bblockx3.hpp"
+#include "common.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+namespace sncal {
+namespace {
+
+typedef __bf16 xh_t;                                                  // the 16-bit type of the split
+typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 h16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define BBX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+constexpr int TH = 16, TW = 14;                     // output tile
+constexpr int MH = TH + 2, MW = 16;                 // mid tile (rows, fragment width)
+constexpr int XH = TH + 4, XW = 18;                 // x halo tile
+constexpr int PXB = 96;                             // bytes per pixel and plane (48 channels x 16 bit)
+constexpr int X_PITCH = XW * PXB, X_PIECES = 34, X_PLANE = X_PIECES * 1024;     // 34,560 B of pixels per plane in whole 1 KB DMA pieces
+constexpr int M_PITCH = MW * PXB, M_PLANE = MH * M_PITCH;
+constexpr int RING_SLOTS = 4;                       // 2 x BBX_STEPS is a multiple: a step's slot is a compile-time constant
+constexpr int OFF_X = 0, OFF_M = OFF_X + 2 * X_PLANE, OFF_RING = OFF_M + 2 * M_PLANE;
+constexpr int OFF_BIAS = OFF_RING + RING_SLOTS * BBX_STEP_BYTES, OFF_CTRL = OFF_BIAS + 96 * 4, LDS_BYTES = OFF_CTRL + 64;
+constexpr int NW = 8;                               // multiplying waves (two per SIMD); wave NW is the loader
+constexpr int J1 = (MH + NW - 1) / NW, J2 = TH / NW;                          // pixel fragments (tile rows) per wave: conv1 (at most), conv2
+constexpr int NSUB = 3 * BBX_STEPS - 1;             // sub-steps of a convolution: (cross u0, cross u1, main) per step, no cross for the zero unit
+static_assert(XH * X_PITCH <= X_PLANE && (2 * BBX_STEPS) % RING_SLOTS == 0 && TH % NW == 0 && J1 == J2 + 1 && LDS_BYTES <= 160 * 1024, "layout");
+enum { C_WREADY = 0, C_XREADY = 2, C_XFREE = 3, C_MID = 4, C_WDONE = 8 };          // C_WDONE + w: steps wave w has finished reading (a SUM over waves
+                                                                                       // would let seven fast waves vouch for a slow one)
+
+// One LDS-DMA piece (64 lanes x 16 bytes -> 1 KB at LDS byte address `lds_addr`) as inline assembly: hipcc's wait-count pass does not
+// see it, so the loader's counter polls are not preceded by vmcnt(0); every wait of this kernel is explicit.
+__device__ __forceinline__ void dma_piece(i32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4_t raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return i32x4_t{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned poll(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void spin_until(unsigned* p, unsigned target) {
+    while ((int)(poll(p) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void split4(const float (&v)[4], h16x4& hi, h16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (xh_t)v[e]; lo[e] = (xh_t)(v[e] - (float)hi[e]); }
+}
+
+__global__ __launch_bounds__(64 * (NW + 1)) void bblockx3_kernel(const BBlockX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* const ctrl = reinterpret_cast<unsigned*>(smem + OFF_CTRL);
+    float* const s_bias = reinterpret_cast<float*>(smem + OFF_BIAS);
+    if (tid < 16) ctrl[tid] = 0u;
+    if (tid < 96) s_bias[tid] = tid < 48 ? p.b1[tid] : p.b2[tid - 48];
+    __syncthreads();
+
+    // tiles of this workgroup: the launch's tiles are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8); the
+    // workgroups of an XCD take consecutive tiles of its range, so neighbouring halos meet in one L2
+    const int per_xcd = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, wx = (int)blockIdx.x >> 3;
+    const int n_tiles = p.N * p.tiles_y * p.tiles_x;
+    const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
+    const int t0 = t_lo + wx;
+    if (t0 >= t_hi) return;
+    const int my_tiles = (t_hi - t0 + per_xcd - 1) / per_xcd;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)smem;
+    const unsigned img_twin = (unsigned)(p.H * p.W * 192);
+
+    if (wave == NW) {
+        // ---------------------------------------------------------------- the loader wave ------------------------------------------
+        const i32x4_t rs_w1 = raw_rsrc(p.w1, BBX_W_BYTES), rs_w2 = raw_rsrc(p.w2, BBX_W_BYTES);
+        auto issue_halo = [&](int t) {
+            const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
+            const int oy0 = ty * TH - 2, ox0 = tx * TW - 2;
+            const i32x4_t rs = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_twin, img_twin);
+            for (int piece = 0; piece < X_PIECES; ++piece) {
+                // LDS slot q of a plane = pixel q / 6 of the 20 x 18 halo (row-major), 16-byte slot q % 6 = (group, half) of its 48 channels;
+                // the twin keeps [hi half 0 | hi half 1 | lo half 0 | lo half 1] per group: hi plane from +0 / +16, lo plane from +32 / +48
+                const unsigned q = (unsigned)(piece * 64 + lane);
+                const unsigned px = (q * 43691u) >> 18, sl = q - px * 6u;                  // q / 6 for q < 2^16
+                const unsigned row = (px * 3641u) >> 16, col = px - row * 18u;            // px / 18 for px < 2^12
+                const int iy = oy0 + (int)row, ix = ox0 + (int)col;
+                const bool ok = (px < (unsigned)(XH * XW)) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned voff = ok ? (unsigned)((iy * p.W + ix) * 192) + (sl >> 1) * 64u + (sl & 1u) * 16u : 0x80000000u;
+                dma_piece(rs, lds0 + OFF_X + piece * 1024, voff, 0u);
+                dma_piece(rs, lds0 + OFF_X + X_PLANE + piece * 1024, voff, 32u);
+            }
+        };
+        auto publish = [&](int word, unsigned v) { if (lane == 0) __hip_atomic_store(ctrl + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        // Every request of this wave completes in order.  After the six pieces of step g are issued, `vmcnt(12)` leaves at most the
+        // pieces of steps g - 1 and g in flight: steps <= g - 2 have landed, and so has a halo requested before step g - 1.
+        issue_halo(t0);
+        int halo_pub_at = 1;                         // global step after whose wait the halo in flight is known to have landed
+        unsigned halos = 1;
+        unsigned g = 0;
+        for (int ti = 0; ti < my_tiles; ++ti) {
+            for (int s = 0; s < 2 * BBX_STEPS; ++s, ++g) {
+                if (g >= (unsigned)RING_SLOTS) {                                        // every wave is done with the slot's previous step
+                    const unsigned need = g - RING_SLOTS + 1u;
+                    while (__builtin_amdgcn_ballot_w64((int)(poll(ctrl + C_WDONE + (lane & (NW - 1))) - need) >= 0) != ~0ull) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                }
+                const unsigned slot = g & (RING_SLOTS - 1);
+                const i32x4_t rs = s < BBX_STEPS ? rs_w1 : rs_w2;
+                const unsigned src = (unsigned)((s < BBX_STEPS ? s : s - BBX_STEPS) * BBX_STEP_BYTES);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dma_piece(rs, lds0 + OFF_RING + slot * BBX_STEP_BYTES + i * 1024, (unsigned)(lane * 16), src + i * 1024);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                if (g >= 1u) publish(C_WREADY, g - 1u);
+                if ((int)g == halo_pub_at) publish(C_XREADY, halos);
+                if (s == BBX_STEPS + 4 && ti + 1 < my_tiles) {
+                    // every multiplying wave is past step 14 of this tile (the ring holds four steps), i.e. has read its residual out
+                    // of the halo region: the next tile's halo lands under conv2
+                    spin_until(ctrl + C_XFREE, (unsigned)NW * (unsigned)(ti + 1));
+                    issue_halo(t0 + (ti + 1) * per_xcd);
+                    halo_pub_at = (int)g + 2;
+                    ++halos;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(C_WREADY, g);
+        return;
+    }
+
+    // -------------------------------------------------------------------- the multiplying waves -----------------------------------
+    const int ln = lane & 15, o = lane >> 4, ln2 = ln < TW ? ln : TW - 1;         // conv2: lanes 14 / 15 recompute column 13 and are not stored
+    const unsigned lane_in = (unsigned)((o & 1) * 16);
+    // per-lane LDS byte offsets of the B fragments: [row j] cross-term fragment ([x_lo | x_hi]: octets 0, 1 from the lo plane) and the four
+    // main-term variants (octets 2, 3 = the partner unit: same pixel / next row / next pixel / next group)
+    unsigned bc1[J1], bh1[J1][4], bc2[J2], bh2[J2][4];
+#pragma unroll
+    for (int j = 0; j < J1; ++j) {
+        const int f = wave + NW * j < MH ? wave + NW * j : MH - 1;
+        const unsigned h0 = (unsigned)(OFF_X + f * X_PITCH + ln * PXB) + lane_in;
+        bc1[j] = h0 + (o < 2 ? (unsigned)X_PLANE : 0u);
+        bh1[j][0] = h0; bh1[j][1] = h0 + (o >= 2 ? (unsigned)X_PITCH : 0u); bh1[j][2] = h0 + (o >= 2 ? (unsigned)PXB : 0u); bh1[j][3] = h0 + (o >= 2 ? 32u : 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < J2; ++j) {
+        const int r = wave + NW * j;
+        const unsigned h0 = (unsigned)(OFF_M + r * M_PITCH + ln2 * PXB) + lane_in;
+        bc2[j] = h0 + (o < 2 ? (unsigned)M_PLANE : 0u);
+        bh2[j][0] = h0; bh2[j][1] = h0 + (o >= 2 ? (unsigned)M_PITCH : 0u); bh2[j][2] = h0 + (o >= 2 ? (unsigned)PXB : 0u); bh2[j][3] = h0 + (o >= 2 ? 32u : 0u);
+    }
+    const unsigned pa = (unsigned)(OFF_RING + lane * 16), pah = pa + (o >= 2 ? 2560u : 0u);     // A: a unit's fragment / [w_hi(u0) | w_hi(u1)]
+
+    f32x4 acc[3][J1];
+    auto init_acc = [&](int conv) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+            const float4 b = *reinterpret_cast<const float4*>(s_bias + conv * 48 + cb * 16 + o * 4);
+#pragma unroll
+            for (int j = 0; j < J1; ++j) acc[cb][j] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    };
+    auto signal = [&](int word) { if (lane == 0) __hip_atomic_fetch_add(ctrl + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    // One convolution: 14 pair-steps of (cross u0, cross u1, main) sub-steps; J pixel fragments of this wave against the three 16-channel
+    // blocks.  Operand fragments are read one sub-step ahead, the reads interleaved with the MFMAs.  gs0 = global index of its first step.
+    auto conv = [&](auto j_c, auto pitch_c, auto s0_c, const unsigned* bc, const unsigned (*bh)[4], unsigned gs0) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_c)::value, PITCH = decltype(pitch_c)::value, S0 = decltype(s0_c)::value;
+        h16x8 a[2][3], b[2][J];
+        auto load = [&](int k, int buf) __attribute__((always_inline)) {
+            const int s = k < 39 ? k / 3 : 13, part = k < 39 ? k % 3 : (k == 39 ? 0 : 2);
+            const int slot = (S0 + s) & (RING_SLOTS - 1);
+            if (part == 0) spin_until(ctrl + C_WREADY, gs0 + (unsigned)s + 1u);            // the step's weights have landed
+            const BbxUnit u0 = bbx_unit(s, 0);
+            if (part < 2) {
+                const BbxUnit u = bbx_unit(s, part);
+                const int off = u.dy * PITCH + u.dx * PXB + u.g * 32;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) a[buf][cb] = *reinterpret_cast<const h16x8*>(smem + pa + (slot * BBX_STEP_BYTES + part * 3072 + cb * 1024));
+#pragma unroll
+                for (int j = 0; j < J; ++j) b[buf][j] = *reinterpret_cast<const h16x8*>(smem + bc[j] + off);
+            } else {
+                const int ty = s < 9 ? 1 : s < 12 ? 2 : s == 12 ? 3 : 0;
+                const int off = u0.dy * PITCH + u0.dx * PXB + u0.g * 32;
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) a[buf][cb] = *reinterpret_cast<const h16x8*>(smem + pah + (slot * BBX_STEP_BYTES + cb * 1024));
+#pragma unroll
+                for (int j = 0; j < J; ++j) b[buf][j] = *reinterpret_cast<const h16x8*>(smem + bh[j][ty] + off);
+                // (LDS operations of a wave execute in order: the step's last reads are ahead of this)
+                if (lane == 0) __hip_atomic_store(ctrl + C_WDONE + wave, gs0 + (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int k = 0; k < NSUB; ++k) {
+            const int cur = k & 1;
+            if (k + 1 < NSUB) load(k + 1, cur ^ 1);
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[cb][j] = BBX_MFMA(a[cur][cb], b[cur][j], acc[cb][j]);
+            if (k + 1 < NSUB) {
+#pragma unroll
+                for (int i = 0; i < 3 + J; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * J - (3 + J), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool tracing = p.trace != nullptr;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
+
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int t = t0 + ti * per_xcd;
+        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const unsigned gs = (unsigned)ti * 2u * BBX_STEPS;
+        if (tracing) tprev = __builtin_amdgcn_s_memtime();
+        init_acc(0);
+        spin_until(ctrl + C_XREADY, (unsigned)ti + 1u);                   // this tile's halo has landed
+        lap(0);
+        // conv1: mid rows f = wave + 8 j (waves 0 and 1 own three, the others two)
+        if (wave + NW * (J1 - 1) < MH)
+            conv(std::integral_constant<int, J1>{}, std::integral_constant<int, X_PITCH>{}, std::integral_constant<int, 0>{}, bc1, bh1, gs);
+        else
+            conv(std::integral_constant<int, J1 - 1>{}, std::integral_constant<int, X_PITCH>{}, std::integral_constant<int, 0>{}, bc1, bh1, gs);
+        lap(1);
+        // residual = centre of the x halo -> registers (hi + lo), then the halo region is free for the next tile
+        f32x4 res[J2][3];
+#pragma unroll
+        for (int j = 0; j < J2; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const char* px = smem + OFF_X + ((wave + NW * j + 2) * XW + ln + 2) * PXB + cb * 32 + o * 8;
+                const h16x4 rh = *reinterpret_cast<const h16x4*>(px), rl = *reinterpret_cast<const h16x4*>(px + X_PLANE);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[j][cb][e] = (float)rl[e] + (float)rh[e];
+            }
+        signal(C_XFREE);
+        // mid = ReLU(conv1) as hi / lo planes; positions outside the image are conv2's zero padding
+#pragma unroll
+        for (int j = 0; j < J1; ++j) {
+            const int f = wave + NW * j;
+            if (f < MH) {
+                const int iy = oy0 - 1 + f, ix = ox0 - 1 + ln;
+                const bool inimg = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[cb][j][e], 0.f) : 0.f;
+                    h16x4 hi, lo;
+                    split4(v, hi, lo);
+                    char* dst = smem + OFF_M + (f * MW + ln) * PXB + cb * 32 + o * 8;
+                    *reinterpret_cast<h16x4*>(dst) = hi;
+                    *reinterpret_cast<h16x4*>(dst + M_PLANE) = lo;
+                }
+            }
+        }
+        signal(C_MID);
+        init_acc(1);
+        lap(2);
+        spin_until(ctrl + C_MID, (unsigned)NW * ((unsigned)ti + 1u));     // everyone's mid rows are written
+        lap(3);
+        conv(std::integral_constant<int, J2>{}, std::integral_constant<int, M_PITCH>{}, std::integral_constant<int, BBX_STEPS % RING_SLOTS>{}, bc2, bh2, gs + BBX_STEPS);
+        lap(4);
+        // epilogue: + x, ReLU -> split twin (8 + 8 bytes per lane and block: the four lanes of a pixel complete 32-byte halves) and / or fp32
+        const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(p.out_twin ? reinterpret_cast<char*>(p.out_twin) + (size_t)n * img_twin : const_cast<void*>(p.x), 0,
+                                                                                 p.out_twin && !(p.dbg & 1) ? (int)img_twin : 0, 0x00020000);
+        const unsigned img_f32 = (unsigned)(p.H * p.W * p.out_cstride * 4);
+        const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(p.out ? reinterpret_cast<char*>(p.out) + (size_t)n * img_f32 : const_cast<void*>(p.x), 0,
+                                                                                p.out && !(p.dbg & 1) ? (int)img_f32 : 0, 0x00020000);
+        const bool has_tw = p.out_twin != nullptr, has_f = p.out != nullptr;
+#pragma unroll
+        for (int j = 0; j < J2; ++j) {
+            const int oy = oy0 + wave + NW * j, ox = ox0 + ln;
+            const bool ok = (ln < TW) & (oy < p.H) & (ox < p.W);
+            const unsigned vt = ok ? (unsigned)((oy * p.W + ox) * 192 + o * 8) : 0x80000000u;
+            const unsigned vf = ok ? (unsigned)(((oy * p.W + ox) * p.out_cstride + p.out_coff + o * 4) * 4) : 0x80000000u;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[cb][j][e] + res[j][cb][e], 0.f);
+                if (has_tw) {
+                    h16x4 hi, lo;
+                    split4(v, hi, lo);
+                    u32x2 d0 = __builtin_bit_cast(u32x2, hi), d1 = __builtin_bit_cast(u32x2, lo);
+                    asm volatile("" : "+v"(d0), "+v"(d1));
+                    __builtin_amdgcn_raw_buffer_store_b64(d0, rs_tw, vt, cb * 64, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(d1, rs_tw, vt, cb * 64 + 32, 0);
+                    asm volatile("s_nop 3" :: "v"(d0), "v"(d1) : "memory");
+                }
+                if (has_f) {
+                    u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    asm volatile("" : "+v"(d));
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_f, vf, cb * 64, 0);
+                    asm volatile("s_nop 3" :: "v"(d) : "memory");
+                }
+            }
+        }
+        lap(5);
+        tsum[7] += 1;
+    }
+    if (tracing && lane == 0)
+        for (int k = 0; k < 8; ++k) p.trace[((size_t)blockIdx.x * NW + wave) * 8 + k] = tsum[k];
+}
+
+}  // namespace
+
+int launch_bblockx3(const BBlockX3Params& p0, hipStream_t s) {
+    BBlockX3Params p = p0;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.trace = nullptr;
+    static const int dbg = getenv("SNCAL_BBX_DBG") ? atoi(getenv("SNCAL_BBX_DBG")) : 0;
+    p.dbg = dbg;
+    static int n_wgs = 0;
+    if (!n_wgs) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bblockx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_wgs = cus >= 8 ? cus / 8 * 8 : 256;                 // one workgroup per CU, a multiple of the 8 XCDs
+    }
+    static const char* trace_file = getenv("SNCAL_BBX_TRACE");
+    if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * NW * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * NW * 64, s);
+    SNCAL_LAUNCH(bblockx3_kernel, dim3((unsigned)n_wgs), dim3(64 * (NW + 1)), (size_t)LDS_BYTES, s, p);
+    SNCAL_CHECK_LAUNCH();
+    if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run
+        std::vector<unsigned long long> h((size_t)n_wgs * NW * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), p.trace, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(p.trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+    return SNCAL_OK;
+}
+
+}  // namespace sncal

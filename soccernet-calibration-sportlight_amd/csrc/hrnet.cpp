@@ -18,6 +18,7 @@
 #include "ops.hpp"
 #include "head.hpp"
 #include "bblock.hpp"
+#include "bblockx3.hpp"
 #include "conv_tt.hpp"
 
 #include <algorithm>
@@ -55,6 +56,7 @@ struct ConvLayer {
     void* d_w_x3 = nullptr;     // bf16x3 engine: hi / lo split weights in the two-team kernel's fragment order (16-channel stages)
     int x3_blk = TT_COUT;       // ... packed in output-channel blocks of 96 (tile 96 x 8 x 32) or, for widths that are no multiple of 96, 64 (64 x 12 x 32)
     bool x3_on = false;
+    void* d_w_bbx = nullptr;    // bf16x3 engine, 48 -> 48 3x3 layers: pair-step packing of the fused BasicBlock (bblockx3.hip)
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
@@ -137,6 +139,7 @@ struct sncal_hrnet {
     std::vector<char> need_bf16;              // per tensor: some active consumer reads the bf16 tensor
     std::vector<int> producer;                // per tensor: active op that writes it
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
+    bool fuse_bbx3 = getenv("SNCAL_FUSE_BBX3") ? atoi(getenv("SNCAL_FUSE_BBX3")) != 0 : true;         // ... and in split arithmetic (bblockx3.hip), bf16x3 engine
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     void *d_hw0_32 = nullptr, *d_hw1_32 = nullptr;      // head32.hip packing (null when K1 is not a multiple of 16)
     void *d_hw0_32l = nullptr, *d_hw1_32l = nullptr;    // bf16x3 engine (headx3.hip): lo parts of the split weights; d_hw0_32 / d_hw1_32 then hold the hi parts
@@ -631,6 +634,17 @@ int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
                     }
     SNCAL_CHECK_HIP(hipMalloc(&L.d_w_x3, host.size() * 2));
     SNCAL_CHECK_HIP(hipMemcpy(L.d_w_x3, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    return SNCAL_OK;
+}
+
+// bf16x3 engine: the fused 48-channel BasicBlock's own packing of a 48 -> 48 layer (bblockx3.hpp: 14 pair-steps of 6 KB)
+int pack_layer_bbx3(sncal_hrnet& net, ConvLayer& L) {
+    if (L.d_w_bbx) { (void)hipFree(L.d_w_bbx); L.d_w_bbx = nullptr; }
+    if (!x3_shape_ok(net, L) || L.cin != 48 || L.cout != 48) return SNCAL_OK;
+    std::vector<uint16_t> host;
+    bbx3_pack_weights(L.w.data(), L.scale.data(), [](float v, uint16_t* hi, uint16_t* lo) { *hi = f2bf(v); *lo = f2bf(v - bf2f(*hi)); }, host);
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w_bbx, host.size() * 2));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w_bbx, host.data(), host.size() * 2, hipMemcpyHostToDevice));
     return SNCAL_OK;
 }
 
@@ -1495,7 +1509,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_t3) (void)hipFree(L.d_w_t3); if (L.d_oscale) (void)hipFree(L.d_oscale); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_t3) (void)hipFree(L.d_w_t3); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
@@ -1565,6 +1579,8 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         rc = pack_layer_fp8(*net, L);
         if (rc) return rc;
         rc = pack_layer_x3(*net, L);
+        if (rc) return rc;
+        rc = pack_layer_bbx3(*net, L);
         if (rc) return rc;
         std::vector<float>().swap(L.w);
     }
@@ -1833,7 +1849,44 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             if (ok(A) && ok(Bl) && net->tensors[op.in].C == 48 && net->tensors[nx.out].C == 48) op2 = &nx;
                         }
                     }
-                    if (op2) {
+                    // ... and in the bf16x3 engine: conv1 -> mid tile in LDS as hi / lo planes -> conv2 + residual (bblockx3.hip); the mid tensor and
+                    // its twin are not written at all
+                    const Op* opx = nullptr;
+                    if (net->fuse_bbx3 && net->x3 && op.relu && op.res < 0 && !op.out_f32 && oi + 1 < net->ops.size() && net->layers[op.conv].x3_on &&
+                        net->layers[op.conv].d_w_bbx && tt_eligible(*net, op, sb)) {
+                        const Op& nx = net->ops[oi + 1];
+                        if (nx.type == OP_CONV && op_active(*net, nx) && nx.in == op.out && nx.res == op.in && nx.relu && !nx.out_f32 && op.out_coff == 0 &&
+                            net->layers[nx.conv].x3_on && net->layers[nx.conv].d_w_bbx && tt_eligible(*net, nx, sb) && net->tensors[op.in].C == 48 &&
+                            net->tensors[op.in].twin >= 0 && net->tensors[net->tensors[op.in].twin].first >= 0) opx = &nx;
+                    }
+                    if (opx) {
+                        const Tensor& ti = net->tensors[op.in];
+                        const Tensor& to = net->tensors[opx->out];
+                        const sncal::LaunchEvents armed = sncal::launch_events();
+                        sncal::launch_events() = sncal::LaunchEvents{};
+                        if (!twin_written_by_producer(*net, op.in, sb)) {         // the fp32 input's split twin, unless its producer wrote it
+                            rc = launch_split_f32(ws + ti.offset, ws + net->tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream);
+                            if (rc) return rc;
+                        }
+                        sncal::launch_events() = armed;
+                        BBlockX3Params bp;
+                        memset(&bp, 0, sizeof(bp));
+                        bp.x = ws + net->tensors[ti.twin].offset;
+                        const bool twin_out = to.twin >= 0 && net->tensors[to.twin].first >= 0 && twin_written_by_producer(*net, opx->out, sb);
+                        bp.out_twin = twin_out ? ws + net->tensors[to.twin].offset : nullptr;
+                        bp.out = (!twin_out || net->need_bf16[opx->out]) ? reinterpret_cast<float*>(ws + to.offset) : nullptr;
+                        bp.w1 = net->layers[op.conv].d_w_bbx; bp.b1 = net->layers[op.conv].d_bias;
+                        bp.w2 = net->layers[opx->conv].d_w_bbx; bp.b2 = net->layers[opx->conv].d_bias;
+                        bp.N = sb; bp.H = ti.H; bp.W = ti.W; bp.out_cstride = to.C; bp.out_coff = opx->out_coff;
+                        rc = launch_bblockx3(bp, stream);
+                        if (net->profiling) {
+                            net->last_kernel = "bblockx3_fused";
+                            const double px = (double)sb * ti.H * ti.W;
+                            net->last_flops = 2.0 * 2.0 * px * 48 * 48 * 9;
+                            net->last_bytes = px * 48 * 4 * (1.0 + (bp.out_twin ? 1.0 : 0.0) + (bp.out ? 1.0 : 0.0)) + 2.0 * BBX_W_BYTES;
+                        }
+                        skip_next = true;
+                    } else if (op2) {
                         const Tensor& ti = net->tensors[op.in];
                         BBlockParams bp;
                         bp.x = ws + ti.offset; bp.out = ws + net->tensors[op2->out].offset;

@@ -235,6 +235,30 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 # different neighbours (their fp32 sums differ in the last bits) the output moves by ulp(mid) x |w2| ~ 4e-4 per flip
                 check(op['name'] + ' + conv2', got, ref, rel_out, 4e-3, stats, 'bblock48_fused')
                 continue
+            if label == 'bblockx3_fused' and op['kernel'] == 'bblockx3_fused':
+                # bf16x3, fused 48-channel BasicBlock (bblockx3.hip): x (split twin) -> conv1 + shift, ReLU -> mid (split in LDS, never in
+                # HBM) -> conv2 + shift + x, ReLU -> split twin and / or fp32.  Every product good to ~2^-16: 3e-5 of sum |x w| per
+                # convolution, the first one's bound carried through |w2|
+                nxt = by_idx[op['idx'] + 1]
+                assert nxt['type'] == 'conv' and nxt['in'] == op['out'] and nxt['res'] == op['in'], 'fused block shape'
+                fused_second.add(nxt['idx'])
+                w2, shift2 = W.get(nxt)
+                xin = _split_twin_value(taps[(nxt['idx'], ti['twin'])])
+                mid = torch.relu(conv_ref(xin, w, 1) + shift[None, :, None, None])
+                y = torch.relu(conv_ref(mid, w2, 1) + shift2[None, :, None, None] + xin)
+                slack = 3e-5 * conv_ref(mid.abs(), w2.abs(), 1) + conv_ref(3e-5 * conv_ref(xin.abs(), w.abs(), 1), w2.abs(), 1)
+                to = net.plan_tensor(nxt['out'])
+                name = f"{op['name']} + conv2 {to['H']}x{to['W']} 48->48->48"
+                checked = False
+                if to['alive'] and _bf16_written(net, ops, nxt):
+                    got = nchw(taps[(nxt['idx'], nxt['out'])])[:, nxt['out_coff']:nxt['out_coff'] + 48]
+                    check(name, got, y, rel_out, abs_out + slack, stats, 'bblockx3_fused')
+                    checked = True
+                if to['twin'] >= 0 and net.plan_tensor(to['twin'])['alive'] and (nxt['idx'], to['twin']) in taps:
+                    check(name + ' [split twin out]', _split_twin_value(taps[(nxt['idx'], to['twin'])]), y, 1e-5 + 2.0 ** -16, abs_out + slack, stats, 'bblockx3_fused split out')
+                    checked = True
+                assert checked, name
+                continue
             if op['fp8']:
                 tw = net.plan_tensor(ti['twin'])
                 xin = e4m3_decode(T(op, ti['twin'])).permute(0, 3, 1, 2).contiguous()            # codes
@@ -496,16 +520,16 @@ def test_every_launch_of_the_fp32_engine_w18(sncal, cuda):
 
 def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
     """The fp32-class engine: fp32 tensors everywhere, the 3x3 stride-1 convolutions of stages 2-4 (wide branches and the 48-channel
-    branch, as 64-channel x 12-row tiles) on the two-team kernel in split-bf16 arithmetic -- each against torch fp32 on the
+    branch as fused BasicBlocks, bblockx3.hip) in split-bf16 arithmetic -- each against torch fp32 on the
     split twin it reads (hi + lo; written by the producing convolution's epilogue or by split_f32_kernel), its fp32 output and the
     split twin it hands on."""
     sd = _weights('hrnet_w48')
     stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'bf16x3', tag='w48 540p bf16x3')
     _report(stats, 'bf16x3_w48_540p')
-    k, k48 = 'conv_tt<bf16x3,k3,s1,8x32x96>', 'conv_tt<bf16x3,k3,s1,12x32x64>'   # 144 wide + 64 48-channel convolutions, each checked on its fp32 output, its twin, or both
+    k, kb = 'conv_tt<bf16x3,k3,s1,8x32x96>', 'bblockx3_fused'   # 144 wide convolutions + 32 fused 48-channel blocks, each checked on its fp32 output, its twin, or both
     n = lambda key: stats.get(key, {'ops': 0})['ops']
-    assert n(k) + n(k48) >= 20 and n(k + ' split out') + n(k48 + ' split out') >= 150      # (fp32 outputs: module ends only)
-    assert n(k) + n(k + ' split out') >= 144 and n(k48) + n(k48 + ' split out') >= 64
+    assert n(k) >= 12 and n(k + ' split out') >= 120                                         # (fp32 outputs: module ends only)
+    assert n(k) + n(k + ' split out') >= 144 and n(kb) + n(kb + ' split out') >= 32 and n(kb) >= 8 and n(kb + ' split out') >= 24
 
 
 def test_every_launch_of_the_bf16x3_engine_w32_270p(sncal, cuda):
@@ -525,10 +549,10 @@ def test_every_launch_of_the_bf16x3_engine_w48_1080p_and_odd_sizes(sncal, cuda):
     sd = _weights('hrnet_w48')
     stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(2, 1080, 1920, 20, cuda), 'bf16x3', tag='w48 1080p bf16x3')
     _report(stats, 'bf16x3_w48_1080p')
-    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and 'conv_tt<bf16x3,k3,s1,12x32x64> split out' in stats
+    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24 and stats['bblockx3_fused']['ops'] >= 8
     stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(5, 270, 500, 21, cuda), 'bf16x3', tag='w48 270x500 bf16x3')
     _report(stats, 'bf16x3_w48_270x500')
-    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats
+    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24
 
 
 def test_every_launch_of_the_bf16x3_engine_w18_and_line_net(sncal, cuda):

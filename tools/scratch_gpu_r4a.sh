@@ -1,10 +1,8 @@
 #!/bin/bash
-O=gpurun_out/r4b; mkdir -p $O
-for nth in 0 1 7; do
-SNCAL_TT_TRACE=$O/tt_c32_$nth.bin SNCAL_TT_TRACE_NTH=$nth python tools/dev/tt_trace_run.py bf16x3 64 > $O/tt.log 2>&1
-(echo "=== c32 launch $nth"; python tools/tt_trace.py $O/tt_c32_$nth.bin; python tools/tt_pipe.py $O/tt_c32_$nth.bin | head -8) > $O/tt_c32_$nth.txt 2>&1
-SNCAL_TT_TRACE=$O/tt_c23_$nth.bin SNCAL_TT_TRACE_CFG64=1 SNCAL_TT_TRACE_NTH=$nth python tools/dev/tt_trace_run.py bf16x3 64 > $O/tt.log 2>&1
-(echo "=== c23 launch $nth"; python tools/tt_trace.py $O/tt_c23_$nth.bin; python tools/tt_pipe.py $O/tt_c23_$nth.bin | head -8) > $O/tt_c23_$nth.txt 2>&1
-done
-cat $O/tt_c32_*.txt $O/tt_c23_*.txt
-rm -f $O/*.bin
+O=gpurun_out/r4d; mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "bf16x3_engine_w48_540p" > $O/pytest.txt 2>&1; tail -30 $O/pytest.txt
+timeout 300 python -m pytest tests/test_hrnet_gpu.py -m gpu -x -q -k "x3" > $O/pytest2.txt 2>&1; tail -5 $O/pytest2.txt
+for i in 1 2; do
+echo "--- new"; DEV_TOP=8 timeout 300 python tools/dev_bench.py 64 bf16x3 5
+echo "--- unfused"; SNCAL_FUSE_BBX3=0 DEV_TOP=8 timeout 300 python tools/dev_bench.py 64 bf16x3 5
+done 2>&1 | grep -v amdgpu.ids | tee $O/ab.txt

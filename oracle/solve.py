@@ -45,16 +45,19 @@ from .pitch import GOAL_LEFT, GOAL_RIGHT, GROUND, KEEP_POINTS, TOP_GATES, pitch_
 # bound the UNPINNED gap to OpenCV: `opencv_stops()` = calibrateCamera's default criteria of 30 joint iterations and
 # solvePnPRefineLM's criteria (20000, 1e-5) on step and residual (SURVEY 8c notes; the damping schedule stays the build's
 # own); `iac_failure='reference'` = go on with K = I as prediction.py:514 does.
-STOP = dict(schedule='opencv', joint_iters=30, pose_iters=200, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
+STOP = dict(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
 COUNTERS = dict(iac_failures=0, refine_cap_hits=0)
 FLT_EPSILON = 1.1920928955078125e-07
 DBL_EPSILON = 2.220446049250313e-16
 
 
-def opencv_stops(pose_iters=200):
-    """pose_iters: cap of refine_camera's LMSolver run.  The reference passes 20000 (camera.py:116); the build's default is 200
-    (shared with solve.hip, sncal_voter_cfg.refine_max_iters): well-posed frames stop on the 1e-5 step test within ~25 iterations,
-    the runs that reach a cap are poses refined under a degenerate calibration, where LMSolver alternates lambda = 0 / lambda_c.
+def opencv_stops(pose_iters=20000):
+    """pose_iters: cap of refine_camera's LMSolver run = the reference's 20000 (camera.py:116; shared with solve.hip,
+    sncal_voter_cfg.refine_max_iters; rounds 1-3 capped it at 200).  Well-posed frames stop on the 1e-5 step test within ~25
+    iterations; the runs that used to reach the cap were poses refined under a degenerate calibration (f ~ 0.04 px candidates of the
+    voter: LMSolver crawls through reject / accept / accept rounds that gain 1e-4 of the error each) -- those candidates are no longer
+    refined at all (camera_all_points: their focal length fails good_camera whatever the pose), the few that remain are slow fits
+    of real cameras, which the reference runs to the end as well.
     DEFAULT since round 3: the minimisers follow OpenCV 4.7's own schedules as far as they are known (SURVEY 8c notes, restated
     from the upstream sources from memory -- still UNPINNED): LMSolver for solvePnPRefineLM (lm_solver_pose), CvLevMarq for the
     extrinsics refinements (cvlevmarq_pose, 20 iterations / FLT_EPSILON) and for calibrateCamera's joint fit (30 / DBL_EPSILON)."""
@@ -430,6 +433,7 @@ def lm_solver_pose(R, t, K4, X, uv, max_iters=20000, eps=1e-5):
         it += 1
         if not (it < max_iters and np.abs(d).max() >= eps and np.abs(r).max() >= eps):
             break
+    COUNTERS['refine_iters_max'] = max(COUNTERS.get('refine_iters_max', 0), it)
     if it >= max_iters:
         COUNTERS['refine_cap_hits'] += 1
     return exp_so3(x[:3]), x[3:].copy()
@@ -476,7 +480,7 @@ def cvlevmarq_pose(R, t, K4, X, uv, max_iter=20, eps=FLT_EPSILON):
 
     def solve_step(ne, lam):
         A, g = ne
-        return chol_solve(A + lam * np.diag(np.diag(A)), g)
+        return sym_solve(A + lam * np.diag(np.diag(A)), g)        # cv::solve(..., DECOMP_SVD): a step even when not positive definite
     x = _cvlevmarq(evaluate, solve_step, np.r_[log_so3(R), t].astype(np.float64), max_iter, eps)
     return exp_so3(x[:3]), x[3:].copy()
 
@@ -508,9 +512,7 @@ def _joint_cvlevmarq(views, weights, f, poses, cx, cy, max_iter, eps):
         s_aff, s_g, sol = aff * (1 + lam), gf, []
         for A_, B_, g_ in blocks:
             Ad = A_ + lam * np.diag(np.diag(A_))
-            ab, ag = chol_solve(Ad, B_), chol_solve(Ad, g_)
-            if ab is None or ag is None:
-                return None
+            ab, ag = sym_solve(Ad, B_), sym_solve(Ad, g_)      # (OpenCV: one dense SVD solve; the pose blocks never abort the step)
             s_aff -= float(B_ @ ab)
             s_g -= float(B_ @ ag)
             sol.append((ab, ag))
@@ -845,7 +847,10 @@ def camera_all_points(ids, uv, img_wh=(960, 540)):
             raise RuntimeError('calibrateCamera failed')
         cam = _cam_from_calibration(res, img_wh)
         cam.solve_pnp(ids, uv)                       # always (Q2)
-        if len(ids) > 6:
+        # Same outcome, less work (shared with solve.hip): every caller keeps this camera only if good_camera accepts it, and its
+        # focal-length clause does not depend on the pose -- a candidate whose calibration fell outside [10, 20000] px is discarded
+        # whatever refine_camera does to it, so it is not refined (under f ~ 0.04 px the reference's 20000-iteration LM runs to the end)
+        if len(ids) > 6 and 10 <= cam.calibration[0, 0] <= 20000:
             cam.refine_camera(ids, uv)
         return cam, cam.projection_rmse(ids, uv)
     except Exception:

@@ -55,9 +55,14 @@ FLOP_LINE_NET = 2 * 185690000000
 FLOP_KEYPOINT_NET_1080P = 2 * 1014180000000
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'f32': 157.3, 'fp8': 5000.0, 'bf16x3': 2500.0 / 3.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
 BATCH = 64
+# make_submit.py:45-50, plus ONE explicit opt-in of the bench: refine_camera's LM stops after REFINE_CAP iterations where the library
+# default is the reference's 20000 (camera.py:116).  A pose that crawls (a slow fit gaining ~1e-4 of its error per round) keeps ONE
+# wavefront busy for ~600 ms at 20000 iterations, and the step is as slow as its slowest frame; what the cap changes is measured on
+# the benchmarked frames outside the timed region and reported on the line (`config.solver.refine_cap`).
+REFINE_CAP = 200
 SOLVER_KW = dict(conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter', lines_file=None,
                  max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0, min_points_per_plane=6,
-                 min_points_for_refinement=6, reliable_thresh=57)          # make_submit.py:45-50
+                 min_points_for_refinement=6, reliable_thresh=57, refine_max_iters=REFINE_CAP)
 
 
 def seeded_weights(cfg, seed):
@@ -154,7 +159,7 @@ def cpu_baseline(sd, cfg_name, frames, kpts, budget_s=45.0, nb=8):
         env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
 
         def run_pool(n, per):
-            procs = [subprocess.Popen([sys.executable, worker, path, str(i * per), str(per)], stdout=subprocess.PIPE, env=env)
+            procs = [subprocess.Popen([sys.executable, worker, path, str(i * per), str(per), str(REFINE_CAP)], stdout=subprocess.PIPE, env=env)
                      for i in range(n)]
             outs = [p.communicate()[0].decode().split() for p in procs]
             return [float(o[0]) for o in outs], sum(int(o[1]) for o in outs)
@@ -512,6 +517,23 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     solve_ms = ev[0].elapsed_time(ev[1]) / 3
+    # the same keypoints under the reference's own refine criterion (20000 iterations, the library default): time and what moves
+    cap_note = None
+    if rank == 0 and not diag:
+        cc_ref = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **dict(SOLVER_KW, refine_max_iters=20000))
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev2[0].record()
+        rec_ref = cc_ref.solve_device(kp_fast)
+        ev2[1].record()
+        torch.cuda.synchronize()
+        ra, rb = cc.records(rec_tmp), cc_ref.records(rec_ref)
+        both = [(a, b) for a, b in zip(ra, rb) if a.status != 0 and b.status != 0]
+        cap_note = {'refine_max_iters': REFINE_CAP, 'library_default': 20000,
+                    'solve_ms_per_batch_at_20000': round(ev2[0].elapsed_time(ev2[1]), 1),
+                    'cameras_with_either': sum(1 for a, b in zip(ra, rb) if a.status != 0 or b.status != 0),
+                    'none_ness_changes': sum(1 for a, b in zip(ra, rb) if (a.status == 0) != (b.status == 0)),
+                    'cameras_rmse_rel_delta_gt_1e-4': sum(1 for a, b in both if abs(a.rmse - b.rmse) > 1e-4 * max(b.rmse, 1e-12)),
+                    'note': 'explicit opt-in of the bench; the library default is the reference criterion (20000, 1e-5)'}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -554,7 +576,7 @@ def main():
                     'random-init HRNet-W48 plus one matched-filter signal path -> peaked heatmaps; see bench.py docstring)',
             'config': {'workload': wl, 'frames_per_gpu': B, 'lanes': L,
                        'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
-                       'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}',
+                       'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}', 'solver': {'refine_cap': cap_note},
                        'decoded_within_8px_of_stamp': round(hit, 4), 'visible_keypoint_conf_median': round(float(np.median(conf_vis)), 4),
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * flop_frame / 1e12, 1),
                        'kernel_time_share_last_warmup_step': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(warm, key=lambda q: -q['ms'])[:8]}},

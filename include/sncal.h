@@ -244,16 +244,16 @@ typedef struct {              /* CameraCreator kwargs, make_submit.py:45-50     
                                  LMSolver for solvePnPRefineLM (lambda_0 = 1, D fixed, gain ratio, stop 1e-5), CvLevMarq for the
                                  extrinsics refits (20 iterations / FLT_EPSILON) and calibrateCamera's joint fit (30 / DBL_EPSILON);
                                  1 = run every minimiser to convergence (the build's round-1/2 specification).  OpenCV parity is
-                                 unpinned either way (cv2 is not installable offline)                                         */
-    int refine_max_iters;     /* iteration cap of Camera.refine_camera's LM under lm_schedule 0; 0 = 200.  The reference passes
-                                 20000 (camera.py:116): well-posed frames stop on the 1e-5 step test within ~25 iterations, but a
-                                 pose refined under a degenerate calibration (f ~ 20 px candidates the voters discard later) makes
-                                 LMSolver alternate lambda = 0 / lambda_c for the full 20000 -- ~100 ms of one wavefront for a
-                                 camera nobody uses.  The cap's effect is measured oracle-vs-oracle                  */
+                                 unpinned either way (cv2 is not installable offline).  ABI note: 0 became the OpenCV schedules in
+                                 round 3 -- a caller that zero-initialises this struct gets them; set 1 for the round-1/2 behaviour */
+    int refine_max_iters;     /* iteration cap of Camera.refine_camera's LM under lm_schedule 0; 0 = 20000 = what the reference passes
+                                 (camera.py:116; rounds 1-3 defaulted to 200).  Well-posed frames stop on the 1e-5 step test within
+                                 ~25 iterations; the runs that used to need the cap were voter candidates calibrated to f ~ 0.04 px,
+                                 which good_camera discards whatever their pose: those are no longer refined at all              */
 } sncal_voter_cfg;
 
 /* Camera.refine_camera  baseline/camera.py:105-119 (cv.solvePnPRefineLM, K fixed, 6-DoF pose LM; LMSolver's schedule, see
- * sncal_voter_cfg.lm_schedule; max_iters <= 0 / eps <= 0 select (200, 1e-5) -- the reference passes (20000, 1e-5), see sncal_voter_cfg.refine_max_iters; the environment variable
+ * sncal_voter_cfg.lm_schedule; max_iters <= 0 / eps <= 0 select the reference's (20000, 1e-5), see sncal_voter_cfg.refine_max_iters; the environment variable
  * SNCAL_SOLVE_SCHEDULE=converged switches this entry and sncal_solve_pnp to the run-to-convergence minimisers).
  *   d_K (B,4) fx,fy,cx,cy   d_pts3d (B,N,3) fp64   d_pts2d (B,N,2) fp64   d_npts (B) int32
  *   d_rt (B,12) in/out: rotation row-major (9) + position (3)   d_rmse (B) out mean-L2 px */

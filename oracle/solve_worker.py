@@ -1,6 +1,6 @@
 """One worker of the CPU baseline's solve pool (bench.py cpu_baseline leg): TEST / MEASUREMENT INFRASTRUCTURE ONLY.
 
-    python oracle/solve_worker.py <kpts.npy> <start> <count>
+    python oracle/solve_worker.py <kpts.npy> <start> <count> [refine_max_iters]
 
 Mirrors one of the reference's 16 `ProcessPoolExecutor` workers (/root/reference/src/utils/make_submit.py:25,53-54):
 solves `count` frames of the (n,57,3) keypoint file with the oracle CameraCreator and prints
@@ -22,6 +22,8 @@ from oracle import solve as osolve  # noqa: E402
 def main():
     kp = np.load(sys.argv[1])
     start, count = int(sys.argv[2]), int(sys.argv[3])
+    if len(sys.argv) > 4:                      # the bench's explicit cap on refine_camera's LM (bench.py REFINE_CAP): like for like with the GPU leg
+        osolve.opencv_stops(int(sys.argv[4]))
     oc = osolve.CameraCreatorOracle()
     found = 0
     with contextlib.redirect_stdout(io.StringIO()):

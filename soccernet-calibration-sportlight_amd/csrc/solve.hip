@@ -722,13 +722,14 @@ __device__ void cvlevmarq_pose(u64 mask, double* R, double* t, const K4& k, cons
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) Ad[i][j] = A[i][j] + (i == j ? lam * A[i][i] : 0.0);
-            if (chol_solve<6>(Ad, g, d)) {
+            sym_solve6(Ad, g, d);                               // cv::solve(..., DECOMP_SVD): a step even when not positive definite
+            {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) cand[i] = x[i] - d[i];
                 double A2[6][6], g2[6], r2;
                 pose_normal_eq(mask, cand, k, X, u, v, false, A2, g2, e, r2);
                 have = true;
-            } else { e = INFINITY; have = false; }
+            }
             if (!(e > e_prev)) break;
             if (++kk > 16) break;
         }
@@ -957,11 +958,11 @@ __device__ bool calibrate_planes(int sched, const View* views, int nviews, const
                     for (int i = 0; i < 6; ++i)
 #pragma unroll
                         for (int j = 0; j < 6; ++j) Ad[i][j] = A[vi][i][j] + (i == j ? lam * A[vi][i][i] : 0.0);
-                    ok = chol_solve<6>(Ad, Bv[vi], AiB[vi]) && chol_solve<6>(Ad, g[vi], Aig[vi]);
-                    if (ok) {
+                    // (OpenCV: one dense cv::solve(DECOMP_SVD); a pose block that is not positive definite never aborts the step)
+                    sym_solve6(Ad, Bv[vi], AiB[vi]);
+                    sym_solve6(Ad, g[vi], Aig[vi]);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) { s_aff -= Bv[vi][i] * AiB[vi][i]; s_g -= Bv[vi][i] * Aig[vi][i]; }
-                    }
+                    for (int i = 0; i < 6; ++i) { s_aff -= Bv[vi][i] * AiB[vi][i]; s_g -= Bv[vi][i] * Aig[vi][i]; }
                 }
                 have = ok && !(fabs(s_aff) < 1e-300);
                 if (have) {
@@ -1206,7 +1207,11 @@ __device__ int camera_all_points(u64 mask, const Pts& p, int img_w, int img_h, C
     if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0)) return ST_NONE;
     cam_from_calibration(c, f, R0, t0, img_w, img_h);
     if (!cam_solve_pnp(c, mask, p)) return ST_NONE;            // always runs (quirk Q2)
-    if (popc64(mask) > 6) cam_refine(c, mask, p);
+    // Same outcome, less work (shared with oracle/solve.py): every caller keeps this camera only if good_camera accepts it, and the
+    // focal-length clause does not depend on the pose -- a candidate calibrated outside [10, 20000] px is discarded whatever
+    // refine_camera does to it, so it is not refined (under f ~ 0.04 px the reference's 20000-iteration LM runs to the end: 100 ms of
+    // one wavefront for a camera nobody uses, which is what the 200-iteration cap of rounds 1-3 was for)
+    if (popc64(mask) > 6 && c.fx >= 10 && c.fx <= 20000) cam_refine(c, mask, p);
     c.rmse = cam_rmse(c, mask, p);
     return ST_OK;
 }
@@ -1422,7 +1427,7 @@ __global__ __launch_bounds__(256, 1) void voter_kernel(const float* __restrict__
     Pts p;
     load_points(kp, p);
     p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
-    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 200;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 20000;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1447,7 +1452,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     Pts p;
     load_points(kp, p);
     p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
-    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 200;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 20000;
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
@@ -1622,7 +1627,7 @@ static int launch_pnp(const double* d_K, const double* d_pts3d, const double* d_
 extern "C" int sncal_pnp_refine_lm(const double* d_K, const double* d_pts3d, const double* d_pts2d, const int32_t* d_npts,
                                    int B, int N, double* d_rt, double* d_rmse, int max_iters, double eps, void* stream) {
     const bool cv = env_schedule() == SCHED_OPENCV;      // defaults = the criteria camera.py:116-117 passes: (20000, 1e-5)
-    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : (cv ? 200 : 100),
+    return launch_pnp(d_K, d_pts3d, d_pts2d, d_npts, B, N, d_rt, d_rmse, 0, max_iters > 0 ? max_iters : (cv ? 20000 : 100),
                       eps > 0 ? eps : (cv ? 1e-5 : 1e-10), stream);
 }
 

@@ -77,7 +77,7 @@ class CameraCreator:
         # build-side switch (no reference counterpart): 'opencv' = the minimisers follow OpenCV's own LM schedules (default),
         # 'converged' = every minimiser runs to convergence (sncal_voter_cfg.lm_schedule)
         self.lm_schedule = 'opencv'
-        self.refine_max_iters = 200          # the reference passes 20000 (camera.py:116); see sncal_voter_cfg.refine_max_iters
+        self.refine_max_iters = 20000        # the reference's own criterion (camera.py:116); see sncal_voter_cfg.refine_max_iters
         for key, value in kwargs.items():
             setattr(self, key, value)
         self.stat = {'n': 0, 'frames_4': 0, 'frames_4_6': 0, 'frames_bad_cam': 0}

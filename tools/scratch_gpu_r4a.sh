@@ -1,7 +1,11 @@
 #!/bin/bash
-O=gpurun_out/r4f; mkdir -p $O
-timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "bf16x3_engine_w48" > $O/pytest.txt 2>&1; tail -5 $O/pytest.txt
-SNCAL_BBX_TRACE=$O/bbx.bin python tools/dev/bbx_trace_run.py > $O/log.txt 2>&1
-python tools/bbx_trace.py $O/bbx.bin | tee $O/bbx_trace.txt
-rm -f $O/bbx.bin
-DEV_TOP=3 timeout 300 python tools/dev_bench.py 64 bf16x3 5 2>&1 | grep -v amdgpu.ids
+O=gpurun_out/r4j; mkdir -p $O
+timeout 900 python -m pytest tests/test_solve_gpu.py -m gpu -x -q > $O/pytest.txt 2>&1; tail -8 $O/pytest.txt
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r4j/bench.json'))
+print({k: d[k] for k in ('value','ms_per_step')}, d['config'].get('solve_ms_per_batch'), d['config'].get('cameras_found'), d['roofline']['kernel'], d['roofline']['frac'])
+print(d['parity'])
+print({k:(v['share_of_gpu_time'], v['avg_launch_us']) for k,v in d['kernels'].items()})
+PY
+tail -3 $O/bench.err

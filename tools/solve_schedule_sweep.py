@@ -3,11 +3,12 @@
 
 The solve's arithmetic lives in opencv-python 4.7.0.72 (not installable here).  Since round 3 the oracle (and the HIP kernel, same
 specification) follows OpenCV's own minimiser schedules as far as they are known -- LMSolver for solvePnPRefineLM, CvLevMarq for the
-extrinsics refits and calibrateCamera's joint fit -- with ONE stated cap: refine_camera's LMSolver run stops after 200 iterations
-where the reference passes 20000 (camera.py:116).  This script runs the ORACLE (CPU, numpy) on N synthetic frames (SURVEY 8d recipe:
+extrinsics refits and calibrateCamera's joint fit; refine_camera's LMSolver run has the reference's own criterion (20000, 1e-5)
+since round 4 (rounds 1-3 capped it at 200).  This script runs the ORACLE (CPU, numpy) on N synthetic frames (SURVEY 8d recipe:
 sampled broadcast cameras, sigma-px noise, 3 % outliers) under
-    A  the build's default (OpenCV schedules, refine cap 200, homography camera dropped on an IAC failure)
-    B  A with the reference's literal criteria (20000)          -- only frames where a run of A reached the cap can differ
+    A  the build's default (OpenCV schedules, the reference's 20000-iteration refine criterion since round 4, homography camera
+       dropped on an IAC failure)
+    B  A with the 200-iteration refine cap of rounds 1-3        -- only frames where a run of B reached the cap can differ
     C  the round-1/2 specification: every minimiser to convergence under the build's own x10 / /10 damping
     D  A + the reference's continue-with-K=I on IAC failure (prediction.py:514)
 and reports how many frames change None-ness or move their reprojection error by more than 1e-4 relative.  It BOUNDS the
@@ -40,23 +41,22 @@ def run(seed):
         return (None if cam is None else float(cam.rmse), None if cam is None else cam.tag, solve.COUNTERS['iac_failures'],
                 solve.COUNTERS['refine_cap_hits'])
     with contextlib.redirect_stdout(io.StringIO()):
-        solve.opencv_stops(200)
+        solve.opencv_stops(20000)
         solve.STOP['iac_failure'] = 'drop'
         out['A'] = solve_one()
-        if out['A'][3] > 0:
-            solve.opencv_stops(20000)
-            out['B'] = solve_one()
-        else:
-            out['B'] = out['A']                       # no run reached the cap: B == A by construction
+        solve.opencv_stops(200)
+        out['B'] = solve_one()
+        if out['B'][3] == 0:
+            out['B'] = out['A']                       # no run reached the 200 cap: B == A by construction
         solve.converged_stops()
         out['C'] = solve_one()
         if out['A'][2] > 0:
-            solve.opencv_stops(200)
+            solve.opencv_stops(20000)
             solve.STOP['iac_failure'] = 'reference'
             out['D'] = solve_one()
         else:
             out['D'] = out['A']                       # no IAC failure on this frame
-        solve.opencv_stops(200)
+        solve.opencv_stops(20000)
         solve.STOP['iac_failure'] = 'drop'
     return seed, sigma, out
 
@@ -68,8 +68,8 @@ def main():
     with Pool(procs) as pool:
         res = pool.map(run, range(n), chunksize=8)
     summ = {'frames': n, 'seconds': round(time.time() - t0, 1), 'procs': procs,
-            'note': 'oracle-vs-oracle, every row against A = the build default (OpenCV schedules, refine cap 200, IAC drop); bounds the unpinned OpenCV gap, not OpenCV parity'}
-    for mode, name in (('B', 'refine_cap_20000_vs_200'), ('C', 'converged_minimisers_vs_opencv_schedules'), ('D', 'reference_iac_continue_vs_drop')):
+            'note': 'oracle-vs-oracle, every row against A = the build default (OpenCV schedules, refine criterion 20000, IAC drop); bounds the unpinned OpenCV gap, not OpenCV parity'}
+    for mode, name in (('B', 'refine_cap_200_vs_20000'), ('C', 'converged_minimisers_vs_opencv_schedules'), ('D', 'reference_iac_continue_vs_drop')):
         noneness, moved, rel = 0, 0, []
         tags = 0
         for _, _, o in res:

@@ -378,6 +378,8 @@ def main():
                     help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md 5: '
                          '2 lanes fill kernel tails and launch gaps, but per-kernel HIP-event durations then measure a shared GPU, '
                          'so the roofline object is only meaningful at 1)')
+    ap.add_argument('--dump-gather', default=None,
+                    help='testing aid (tests/test_dist_gpu.py): rank 0 saves its own packed records and the gathered tensor of the last step to this .npz')
     ap.add_argument('--dry-dist', action='store_true',
                     help='launcher / collective self-test on CPU (gloo): the N ranks exchange rank-coded records through the '
                          'path\'s single all_gather and rank 0 prints n_gpus and the ranks it saw; no GPU work, not a bench line')
@@ -502,6 +504,10 @@ def main():
                 m[k] += q[k]
         n.set_profiling(False)
     prof = list(merged.values())
+    if args.dump_gather and use_dist and rank == 0:      # the path's one collective, as it ran in the last timed step
+        from sncal_amd.dist import pack_records
+        np.savez(args.dump_gather, local=pack_records(last[0][0], last[0][1]).cpu().numpy(), gathered=last[0][-1].cpu().numpy(),
+                 world=world, rank=rank)
     if diag:                                             # diagnosis runs print the step time only
         print('diag', diag, round(dt / args.steps * 1e3, 3), 'ms/step')
         return

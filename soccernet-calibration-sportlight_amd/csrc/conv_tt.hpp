@@ -46,10 +46,6 @@ struct TTParams {
 
 void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s, int cfg = 0);      // mode 0 bf16, 1 fp8 (e4m3), 2 x3 (split-bf16, fp32 in / out);
                                                                                                 // cfg 0: 96 channels x 8 rows, 1: 64 x 12 (mode 2 only)
-// three-team kernel (conv_t3.hip, bf16): 16-channel stages, weights [nb][chunk16][tap 9][mb 3][lane 64] x 16 B; team arrays hold 3 teams per workgroup
-void launch_conv_t3(const TTParams& p, int n_wgs, hipStream_t s);
-// two teams, each double-buffered on 16-channel stages (conv_d2.hip, bf16): conv_t3's weight packing, two teams per workgroup
-void launch_conv_d2(const TTParams& p, int n_wgs, hipStream_t s);
 constexpr int TT_TABLE_MAX = 760;       // sum of the members' output channels the LDS bias / scale tables hold
 
 }  // namespace sncal

@@ -52,7 +52,6 @@ struct ConvLayer {
     float* d_oscale = nullptr;
     int stage = 0;              // 2..4 for model.stageN.* layers, 0 otherwise
     bool fp8_on = false;
-    void* d_w_t3 = nullptr;     // three-team kernel (conv_t3.hip): 16-channel stages, [nb][chunk16][tap][mb][lane] x 8 bf16
     void* d_w_x3 = nullptr;     // bf16x3 engine: hi / lo split weights in the two-team kernel's fragment order (16-channel stages)
     int x3_blk = TT_COUT;       // ... packed in output-channel blocks of 96 (tile 96 x 8 x 32) or, for widths that are no multiple of 96, 64 (64 x 12 x 32)
     bool x3_on = false;
@@ -122,8 +121,6 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
-    bool use_conv_d2 = getenv("SNCAL_CONV_D2") ? atoi(getenv("SNCAL_CONV_D2")) != 0 : false;      // bf16: two teams, each double-buffered on 16-channel stages
-    bool use_conv_t3 = getenv("SNCAL_CONV_T3") ? atoi(getenv("SNCAL_CONV_T3")) != 0 : false;      // bf16: three teams / 16-channel stages instead of two / 32
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
@@ -650,26 +647,7 @@ int pack_layer_bbx3(sncal_hrnet& net, ConvLayer& L) {
 
 int pack_layer_tt(sncal_hrnet& net, ConvLayer& L) {
     if (L.d_w_tt) { (void)hipFree(L.d_w_tt); L.d_w_tt = nullptr; }
-    if (L.d_w_t3) { (void)hipFree(L.d_w_t3); L.d_w_t3 = nullptr; }
     if (!tt_shape_ok(net, L)) return SNCAL_OK;
-    {   // three-team kernel: per (96-cout block nb, 16-cin chunk c) one 27 KB stage [tap 9][32-row block 3][lane 64] x 8 bf16
-        const int chunks = L.cin / 16, nblk = L.cout / TT_COUT;
-        std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 3 * 64 * 8, 0);
-        for (int nb = 0; nb < nblk; ++nb)
-            for (int c = 0; c < chunks; ++c)
-                for (int s = 0; s < 9; ++s)
-                    for (int mb = 0; mb < 3; ++mb)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int co = nb * TT_COUT + mb * 32 + (lane & 31);
-                            uint16_t* dst = host.data() + (((((size_t)nb * chunks + c) * 9 + s) * 3 + mb) * 64 + lane) * 8;
-                            for (int e = 0; e < 8; ++e) {
-                                const int ci = c * 16 + (lane >> 5) * 8 + e;
-                                dst[e] = f2bf(L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co]);
-                            }
-                        }
-        SNCAL_CHECK_HIP(hipMalloc(&L.d_w_t3, host.size() * 2));
-        SNCAL_CHECK_HIP(hipMemcpy(L.d_w_t3, host.data(), host.size() * 2, hipMemcpyHostToDevice));
-    }
     const int chunks = L.cin / TT_CIN, nblk = L.cout / TT_COUT;
     std::vector<uint16_t> host((size_t)nblk * chunks * 9 * 2 * 3 * 64 * 8, 0);
     for (int nb = 0; nb < nblk; ++nb)
@@ -1303,22 +1281,11 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     sncal::launch_events() = armed;
     const bool cfg64 = x3 && n == 1 && net.layers[ops[0].conv].x3_blk == 64;   // bf16x3, 48-channel branch: tile 64 x 12 x 32
-    const bool t3 = !fp8 && !x3 && net.use_conv_t3;                         // bf16: three teams, 16-channel stages
-    const bool d2 = !fp8 && !x3 && !t3 && net.use_conv_d2;                  // bf16: two teams, double-buffered 16-channel stages
-    if (t3 || d2)
-        for (int i = 0; i < n; ++i) {
-            const ConvLayer& L = net.layers[ops[i].conv];
-            tp.m[i].w = L.d_w_t3;
-            tp.m[i].chunks = L.cin / 16;
-            tp.m[i].w_bytes = (unsigned)((size_t)(L.cout / TT_COUT) * tp.m[i].chunks * 27 * 1024);
-        }
     if (fp8) key += 1 << 30;                                               // fp8 plans have their own stage counts
-    if (t3) key += 1 << 29;
-    if (d2) key += 1 << 28;
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
-        const int rc = tt_build_plan(net, tp.m, n, pd, t3 ? 3 : 2, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
+        const int rc = tt_build_plan(net, tp.m, n, pd, 2, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }
@@ -1333,9 +1300,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
     if (trace_file && (trace_cfg64 ? cfg64 : n == 3) && (trace_nth < 0 || trace_seen++ == trace_nth) && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
-    if (t3) launch_conv_t3(tp, it->second.n_wgs, stream);
-    else if (d2) launch_conv_d2(tp, it->second.n_wgs, stream);
-    else launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg64 ? 1 : 0);
+    launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg64 ? 1 : 0);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -1367,7 +1332,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : t3 ? "conv_t3<bf16,k3,s1,8x32x96>" : d2 ? "conv_d2<bf16,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
     }
     return SNCAL_OK;
 }
@@ -1509,7 +1474,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_t3) (void)hipFree(L.d_w_t3); if (L.d_oscale) (void)hipFree(L.d_oscale); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);

@@ -106,7 +106,7 @@ def test_c5_w48_1080p_flagship(sncal, cuda):
     """C5 shapes on the flagship network: HRNet-W48 at 1920x1080.  fp32 engine vs the oracle on one frame (identical
     keypoint indices, |dlogp| <= 2e-4); bf16 engine (the fused BasicBlock / head / decode kernels at 270x480 branch
     maps and a 540x960 head) on a small batch: same keypoint cells as the fp32 engine up to the bf16 drift bound used
-    for C3.  fp8 arithmetic is not built."""
+    for C3.  (C5's e4m3 arithmetic and its per-GPU batch: test_c5_per_gpu_share_... below and tests/test_fp8_gpu.py.)"""
     cfg = hr.load_config('hrnet_w48')
     sd = hr.seeded_state_dict(cfg, 1, 1.5)
     x = hr.seeded_input(2, 1080, 1920, 41)
@@ -207,3 +207,70 @@ def test_c4_at_size_w48_keypoint_and_w48_line_networks(sncal, cuda):
     l32.load_state_dict(sd_l)
     h32 = l32(x[:1])[-1]
     assert float((h32 - heat_l[:1]).abs().max()) <= 6e-2
+
+
+def test_c4_per_gpu_share_batch64_w48_keypoint_and_line_networks(sncal, cuda):
+    """C4 at its per-GPU share (512 frames over 8 GPUs = 64 frames per GPU): CalibrationPipeline(HRNet-W48 keypoint net, HRNet-W48 line
+    net) on 64 frames of 960x540 in the fp32-class engine.  Size-independent property: a frame's keypoints, line candidates and camera
+    record do not depend on the batch it travels in (the same frames alone, in a batch of 4, give the same bytes); the device line
+    join equals oracle/lines.py on the line net's own heatmaps for 2 of the frames; cameras are found for the stamped frames."""
+    import bench
+    B = 64
+    sd_k = sncal.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True)
+    sd_l = bench.seeded_weights('line_hrnet_w48', seed=2)
+    frames, expect = sncal.synth.stamped_frames(B, seed=91)
+    x = torch.from_numpy(frames).to(cuda)
+    knet = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16x3', device=cuda)
+    knet.load_state_dict(sd_k)
+    lnet = sncal.HRNetHeatmap('line_hrnet_w48', dtype='bf16x3', device=cuda)
+    lnet.load_state_dict(sd_l)
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, **bench.SOLVER_KW)
+    pipe = sncal.CalibrationPipeline(knet, cc, line_net=lnet, line_sigma=3.0, line_scale=4, line_prob_thre=0.0)
+    kp, rec = pipe.submit(x)[:2]
+    pipe.join()
+    torch.cuda.synchronize()
+    kp, rec = kp.clone(), rec.clone()
+    assert kp.shape == (B, 57, 3)
+    sel = [0, 17, 42, 63]
+    kp4, rec4 = pipe.submit(x[sel].contiguous())[:2]
+    pipe.join()
+    torch.cuda.synchronize()
+    assert torch.equal(kp4, kp[sel]) and torch.equal(rec4, rec[sel])                      # batch independence, byte for byte
+    heat_l = lnet(x[:2])[-1]
+    peaks = sncal.EHMPredictionTransform.mask_heat_points_gauss(heat_l, sigma=3.0)
+    assert np.array_equal(peaks.cpu().numpy()[..., :2], od.line_decode(heat_l.cpu().numpy(), 3.0, 1.0)[..., :2])
+    dev_pts = sncal.lines.lines_to_points_device(peaks, scale=4, prob_thre=0.0)
+    arr = ol.keypoints_array(peaks.cpu().numpy(), scale=4, prob_thre=0.0)
+    assert np.array_equal(dev_pts.cpu().numpy().view(np.uint32), arr.view(np.uint32))     # bit-identical candidates
+    got = cc.records(rec)
+    assert sum(r.status != 0 for r in got) >= B - 4
+    vis = expect[..., 2] > 0
+    near = np.abs(kp.cpu().numpy()[..., :2] - expect[..., :2]).max(-1) <= 8.0
+    assert float(near[vis & (kp.cpu().numpy()[..., 2] >= 0.2)].mean()) >= 0.98
+
+
+@pytest.mark.parametrize('dtype', ['bf16x3', 'fp8'])
+def test_c5_per_gpu_share_batch128_w48_1080p(sncal, cuda, dtype):
+    """C5 at its per-GPU share (1024 frames over 8 GPUs = 128 frames per GPU): HRNet-W48 on 128 frames of 1920x1080 (two sub-batches
+    of 64), fp32-class engine and e4m3 engine.  Size-independent property: a frame's decoded keypoints do not depend on the batch it
+    travels in (frames alone = the same bytes); the fp32-class engine reproduces the oracle's indices on one frame (the e4m3 engine
+    is a tolerance study: most usable rows, tests/test_fp8_gpu.py)."""
+    cfg = hr.load_config('hrnet_w48')
+    sd = hr.seeded_state_dict(cfg, 1, 1.5)
+    B = 128
+    g = torch.Generator(device=cuda)
+    g.manual_seed(505)
+    x = torch.rand((B, 3, 1080, 1920), device=cuda, generator=g)
+    net = sncal.HRNetHeatmap('hrnet_w48', dtype=dtype, device=cuda)
+    net.load_state_dict(sd)
+    if dtype == 'fp8':
+        net.calibrate_fp8(x[:8])
+    _, kp = net.forward(x, want_heat=False, decode_size=(1080, 1920))
+    kp = kp.clone()
+    assert kp.shape == (B, 57, 3) and bool(torch.isfinite(kp).all())
+    sel = [0, 63, 64, 127]                                                                # both sub-batches, their edges
+    _, kps = net.forward(x[sel].contiguous(), want_heat=False, decode_size=(1080, 1920))
+    assert torch.equal(kps, kp[sel])
+    if dtype == 'bf16x3':
+        ref = hr.forward(sd, x[:1].cpu(), cfg).numpy()
+        assert np.array_equal(kp[:1].cpu().numpy()[..., :2], od.keypoint_decode(ref, (1080, 1920))[..., :2])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the per-frame calibration hot path on MI355X (metric of BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c4] [--dtype bf16x3|bf16|fp32|fp8] [--size 540p|1080p]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4] [--dtype fp16x3|bf16|fp32|fp8] [--size 540p|1080p]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of frames already resident in HBM (BASELINE config C3: HRNet-W48,
@@ -17,8 +17,8 @@ pitch template through sampled broadcast cameras, the matched stem filters feed 
 peaked (p ~ 0.99) on known cells for the visible keypoints on top of the random network's noise -- what a trained
 network hands to HRNetPredictionTransform / CameraCreator.  Every convolution runs at its full size on dense data.
 
-Engine.  The benchmarked engine is `bf16x3` (default): fp32 tensors and fp32 accumulation, every product formed on the bf16 matrix
-pipe from split operands (x = hi + lo bf16; hi.hi + hi.lo + lo.hi) -- the fastest engine of the build that returns the fp32 engine's
+Engine.  The benchmarked engine is `fp16x3` (default): fp32 tensors and fp32 accumulation, every product formed on the bf16 matrix
+pipe from split operands (x = hi + lo fp16; hi.hi + hi.lo + lo.hi) -- the fastest engine of the build that returns the fp32 engine's
 keypoint indices (the reference's predict() is fp32, metamodel.py:127-134; north_star asks for bit-identical indices): all usable
 keypoints of the benchmarked frames (`parity` on the line), 19 786 of 19 789 on 1024 frames, the three others being ties below 2e-5 in the
 fp32 heatmap (tools/parity_large.py).  The bf16 throughput engine (3x faster, 1-3 % of the usable keypoints move by one cell on the deep-path workload) and the
@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 FLOP_KEYPOINT_NET = 2 * 253910384640
 FLOP_LINE_NET = 2 * 185690000000
 FLOP_KEYPOINT_NET_1080P = 2 * 1014180000000
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'f32': 157.3, 'fp8': 5000.0, 'bf16x3': 2500.0 / 3.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'f32': 157.3, 'fp8': 5000.0, 'fp16x3': 2500.0 / 3.0}   # dense MFMA peaks (fp8: block-scaled K=64/128 forms), MI355X_MICROARCH.md
 BATCH = 64
 # make_submit.py:45-50, plus ONE explicit opt-in of the bench: refine_camera's LM stops after REFINE_CAP iterations where the library
 # default is the reference's 20000 (camera.py:116).  A pose that crawls (a slow fit gaining ~1e-4 of its error per round) keeps ONE
@@ -285,6 +285,11 @@ def parity_of(kp32, r32, kpf, rf, versus):
             'moved_usable_keypoints': int((~same[usable]).sum()), 'moved_usable_max_px': float(move[usable].max()) if usable.any() else 0.0,
             'index_agreement_all_rows': round(float(same.mean()), 6),
             'conf_abs_delta_max_usable': round(float(np.abs(kp32[..., 2] - kpf[..., 2])[usable].max()) if usable.any() else 0.0, 6),
+            # one-sided?  signed mean of (engine - fp32) confidence on the usable rows, and how many rows cross one of the solver's
+            # thresholds (0.5 / 0.35 / 0.2, prediction.py:245-257) in each direction
+            'conf_signed_delta_mean_usable': float(f'{float((kpf[..., 2] - kp32[..., 2])[usable].mean()):.3e}') if usable.any() else 0.0,
+            'threshold_crossings': {'up': int(sum(((kp32[..., 2] < th) & (kpf[..., 2] >= th)).sum() for th in (0.5, 0.35, 0.2))),
+                                    'down': int(sum(((kp32[..., 2] >= th) & (kpf[..., 2] < th)).sum() for th in (0.5, 0.35, 0.2)))},
             'cameras_both': len(both), 'cameras_fp32': sum(r.status != 0 for r in r32), 'cameras_engine': sum(r.status != 0 for r in rf),
             'rmse_rel_delta_max': float(f'{max(deltas):.3e}') if deltas else None,
             'rmse_rel_delta_median': float(f'{float(np.median(deltas)):.3e}') if deltas else None,
@@ -293,8 +298,8 @@ def parity_of(kp32, r32, kpf, rf, versus):
 
 
 def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, flop_frame=None, main_dtype='bf16'):
-    """(parity of the benchmarked engine, fp32 object, bf16x3 object).  fp32 = the reference's own arithmetic (HRNetMetaModel.predict
-    is fp32, metamodel.py:127-134) on the exact-fp32 MFMA engine, load_model's default; bf16x3 = the fp32-class engine (split-bf16
+    """(parity of the benchmarked engine, fp32 object, fp16x3 object).  fp32 = the reference's own arithmetic (HRNetMetaModel.predict
+    is fp32, metamodel.py:127-134) on the exact-fp32 MFMA engine, load_model's default; fp16x3 = the fp32-class engine (split-fp16
     3x3 convolutions), with its own parity against fp32."""
     VS = ('exact-fp32 engine of this build (pinned to the reference goldens by tests/test_hrnet_gpu.py, kernel by kernel to torch fp32 by '
           'tests/test_kernels_gpu.py)')
@@ -303,11 +308,11 @@ def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, 
                                  steps, flop_frame)
     rf = cc.records(cc.solve_device(kp_fast))      # both keypoint sets through the same solve call (no line points): like for like in every workload
     parity = parity_of(kp32, r32, kp_fast.cpu().numpy(), rf, VS)
-    # the other fast engine of the build on the same frames, with its own parity: bf16x3 when bf16 / fp8 is benchmarked, bf16 when bf16x3 is
-    WHAT = {'bf16x3': 'the same step on the fp32-class engine: fp32 tensors and accumulation, every convolution and the head in split-bf16 arithmetic '
-                      '(x = hi + lo bf16; hi.hi + hi.lo + lo.hi on the bf16 matrix pipe; peak = bf16 dense peak / 3 products)',
+    # the other fast engine of the build on the same frames, with its own parity: fp16x3 when bf16 / fp8 is benchmarked, bf16 when fp16x3 is
+    WHAT = {'fp16x3': 'the same step on the fp32-class engine: fp32 tensors and accumulation, every convolution and the head in split-fp16 arithmetic '
+                      '(x = hi + lo fp16; hi.hi + hi.lo + lo.hi on the 16-bit matrix pipe; peak = fp16 dense peak / 3 products)',
             'bf16': 'the same step on the bf16 throughput engine (bf16 tensors, fp32 accumulation): opt-in, NOT index-identical to fp32 -- see its parity'}
-    other = 'bf16' if main_dtype == 'bf16x3' else 'bf16x3'
+    other = 'bf16' if main_dtype == 'fp16x3' else 'fp16x3'
     x3, kp3, r3 = engine_leg(sncal_amd, cfg_name, sd, x, cc, dev, other, PEAK_TFLOPS[other], WHAT[other], steps, flop_frame)
     x3['parity'] = parity_of(kp32, r32, kp3, r3, VS)
     return parity, fp32, other, x3
@@ -364,7 +369,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='bf16x3', choices=['bf16', 'fp32', 'fp8', 'bf16x3'],
+    ap.add_argument('--dtype', default='fp16x3', choices=['bf16', 'fp32', 'fp8', 'fp16x3'],
                     help="fp8: e4m3 arithmetic in the wide 3x3 convolutions (BASELINE config C5; calibrated on the first frames), the rest bf16")
     ap.add_argument('--size', default='540p', choices=['540p', '1080p'], help='input frames 960x540 (the metric) or 1920x1080 (config C5)')
     ap.add_argument('--fp8-layers', default='all', help="layer selection of --dtype fp8 (sncal_hrnet_set_fp8_layers)")
@@ -606,7 +611,7 @@ def main():
             tf = p['flops'] / (p['ms'] * 1e-3) / 1e12
             gbs = p['bytes'] / (p['ms'] * 1e-3) / 1e9
             row = {'share_of_gpu_time': round(p['ms'] / total_ms, 4), 'launches_per_step': p['launches'], 'avg_launch_us': round(p['ms'] * 1e3 / p['launches'], 1),
-                   'tflops': round(tf, 1), 'frac_mfma': round(tf / (PEAK_TFLOPS['fp8'] if 'fp8' in k else PEAK_TFLOPS['bf16x3'] if 'x3' in k else PEAK_TFLOPS['f32' if 'f32' in k else 'bf16']), 4),
+                   'tflops': round(tf, 1), 'frac_mfma': round(tf / (PEAK_TFLOPS['fp8'] if 'fp8' in k else PEAK_TFLOPS['fp16x3'] if 'x3' in k else PEAK_TFLOPS['f32' if 'f32' in k else 'bf16']), 4),
                    'algorithmic_gb_s': round(gbs, 0), 'frac_hbm': round(gbs / 8000.0, 4)}
             if k in pmc:
                 row['pmc_bytes_per_launch'] = pmc[k]

@@ -42,6 +42,10 @@ typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1, SNCAL_FP8 = 2, SNCAL_BF16X3 = 3 } 
 
 int sncal_version(void);
 const char* sncal_last_error(void);
+/* Name of the split-arithmetic engine this library was built with (SNCAL_BF16X3): "fp16x3" (fp16 hi + fp16 lo, the default since round 4)
+ * or "bf16x3" (bf16 hi + lo, -DSNCAL_X3_F16=0).  No reference counterpart: the reference's predict() is plain fp32
+ * (src/models/hrnet/metamodel.py:127-134); the engine reproduces it on the 16-bit matrix pipe. */
+const char* sncal_x3_name(void);
 
 /* ------------------------------------------------------------------------------------------------
  * D1  keypoint heatmap decode

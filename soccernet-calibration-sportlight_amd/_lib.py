@@ -77,6 +77,7 @@ class JpegInfo(ctypes.Structure):
 SIGNATURES = {
     'sncal_version': (ctypes.c_int, []),
     'sncal_last_error': (ctypes.c_char_p, []),
+    'sncal_x3_name': (ctypes.c_char_p, []),
     'sncal_heatmap_decode': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, vp, vp]),
     'sncal_line_decode': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

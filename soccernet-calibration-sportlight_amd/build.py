@@ -30,8 +30,13 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(verbose=False, force=False, jobs=None):
+def build(verbose=False, force=False, jobs=None, x3_f16=None, lib=None, obj=None):
+    """x3_f16=0 / 1 builds the split-arithmetic engine with bf16 / fp16 splits (default: the source's default, fp16) -- an A/B build
+    goes to its own `lib` path and `obj` directory (tools/ab_build.py)."""
+    global OBJ, LIB
+    OBJ, LIB = obj or OBJ, lib or LIB
     hipcc = _hipcc()
+    flags = list(CXXFLAGS) + ([f'-DSNCAL_X3_F16={int(x3_f16)}'] if x3_f16 is not None else [])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h', '.inc'))]
@@ -41,10 +46,10 @@ def build(verbose=False, force=False, jobs=None):
     jobs = jobs or min(6, os.cpu_count() or 1)
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.rsplit('.', 1)[0] + '.o')
-        objs.append(obj)
-        if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
-            cmd = [hipcc, '-x', 'hip', *CXXFLAGS, '-c', src, '-o', obj]
+        o = os.path.join(OBJ, s.rsplit('.', 1)[0] + '.o')
+        objs.append(o)
+        if force or _newer(src, o) or os.path.getmtime(o) < hdr_time:
+            cmd = [hipcc, '-x', 'hip', *flags, '-c', src, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

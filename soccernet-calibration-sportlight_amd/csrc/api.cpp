@@ -1,5 +1,6 @@
 // libsncal.so: version + thread-local error string.
 #include "common.hpp"
+#include "x3.hpp"
 #include <cstring>
 
 namespace sncal {
@@ -15,3 +16,4 @@ LaunchEvents& launch_events() { static thread_local LaunchEvents e; return e; }
 
 extern "C" int sncal_version(void) { return SNCAL_VERSION; }
 extern "C" const char* sncal_last_error(void) { return sncal::g_err; }
+extern "C" const char* sncal_x3_name(void) { return SNCAL_X3_NAME; }

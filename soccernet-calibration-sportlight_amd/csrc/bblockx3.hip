@@ -26,6 +26,7 @@
 // equals conv1 -> twin -> conv2 of the two-kernel path up to the summation order inside the matrix unit.
 #include "bblockx3.hpp"
 #include "common.hpp"
+#include "x3.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -34,14 +35,13 @@
 namespace sncal {
 namespace {
 
-typedef __bf16 xh_t;                                                  // the 16-bit type of the split
-typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 h16x4;
+typedef x3h8 h16x8;                                                   // (x3.hpp: the 16-bit type of the split, fp16 or bf16)
+typedef x3h4 h16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#define BBX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define BBX_MFMA(a, b, c) X3_MFMA_16x16x32(a, b, c)
 
 constexpr int TH = 16, TW = 14;                     // output tile
 constexpr int MH = TH + 2, MW = 16;                 // mid tile (rows, fragment width)
@@ -75,7 +75,7 @@ __device__ __forceinline__ void spin_until(unsigned* p, unsigned target) {
 }
 __device__ __forceinline__ void split4(const float (&v)[4], h16x4& hi, h16x4& lo) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { hi[e] = (xh_t)v[e]; lo[e] = (xh_t)(v[e] - (float)hi[e]); }
+    for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], hi[e], lo[e]);
 }
 
 __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3Params p) {

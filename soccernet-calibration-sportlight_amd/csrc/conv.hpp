@@ -46,6 +46,7 @@
 // LDS-DMA rate (75 KB per chunk at <= 58 B/clk/CU; 54 KB of it weights re-fetched per 192-pixel tile), so a round is bound
 // by DMA throughput during its burst rather than by the latency of its last piece; workgroup lifetime unchanged, removed.
 #pragma once
+#include "x3.hpp"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "common.hpp"
@@ -388,27 +389,23 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 // B fragment -- and WRONG on gfx950 as hipcc 7.2 schedules it: back to back behind the K = 32 instruction whose vDst it
                 // reads as SrcC, with no wait states; accumulator registers 0 and 1 of such tiles came out wrong.  Found by the per-kernel
                 // test, isolated by tools/dev/mfma_pair_probe.hip.)
-                bf16x8 bx[NI], bm[NI];
+                x3h8 bx[NI], bm[NI];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    __bf16 h[4], l[4];
+                    x3h h[4], l[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = b[cur][j][e];
-                        h[e] = (__bf16)x;
-                        l[e] = (__bf16)(x - (float)h[e]);
-                    }
-                    const __bf16 z = (__bf16)0.0f;
-                    bx[j] = bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
-                    bm[j] = bf16x8{h[0], h[1], h[2], h[3], z, z, z, z};
+                    for (int e = 0; e < 4; ++e) X3_SPLIT(b[cur][j][e], h[e], l[e]);
+                    const x3h z = (x3h)0.0f;
+                    bx[j] = x3h8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+                    bm[j] = x3h8{h[0], h[1], h[2], h[3], z, z, z, z};
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const bf16x8 aw = __builtin_bit_cast(bf16x8, a[cur][mi]);
+                    const x3h8 aw = __builtin_bit_cast(x3h8, a[cur][mi]);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bx[j], acc[mi][j], 0, 0, 0);
-                        acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bm[j], acc[mi][j], 0, 0, 0);
+                        acc[mi][j] = X3_MFMA_16x16x32(aw, bx[j], acc[mi][j]);
+                        acc[mi][j] = X3_MFMA_16x16x32(aw, bm[j], acc[mi][j]);
                     }
                 }
             } else {
@@ -593,10 +590,9 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                         u32x4 ov = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                         if constexpr (Elem<T>::X3) {
                             if (has_twin) {        // wave-uniform: [16 hi | 16 lo] bf16 per pixel and 16-channel group, this lane's 4 channels are 8 + 8 bytes
-                                typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
-                                bf4 th, tl;
+                                x3h4 th, tl;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { th[e] = (__bf16)v[e]; tl[e] = (__bf16)(v[e] - (float)th[e]); }
+                                for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], th[e], tl[e]);
                                 const unsigned c16 = (unsigned)(grp * 4) & 15u;          // (nb * CO is a multiple of 16)
                                 const unsigned toff = o == 0x80000000u ? o : o - c16 * 2;  // byte offset of the group's hi half + this lane's 8 bytes
                                 u32x2 t0 = __builtin_bit_cast(u32x2, th), t1 = __builtin_bit_cast(u32x2, tl);
@@ -647,14 +643,13 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
             if constexpr (Elem<T>::X3) {
                 // [16 hi | 16 lo] bf16 per pixel and 16-channel group (conv_tt_body.inc): this lane's 4 channels are 8 + 8 bytes
                 if (p.out_twin) {
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
                     const float v[4] = {v0, v1, v2, v3};
-                    bf4 th, tl;
+                    x3h4 th, tl;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { th[e] = (__bf16)v[e]; tl[e] = (__bf16)(v[e] - (float)th[e]); }
+                    for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], th[e], tl[e]);
                     char* const tw = reinterpret_cast<char*>(p.out_twin) + (pix * p.cout + (co & ~15)) * 4 + (co & 15) * 2;
-                    *reinterpret_cast<bf4*>(tw) = th;
-                    *reinterpret_cast<bf4*>(tw + 32) = tl;
+                    *reinterpret_cast<x3h4*>(tw) = th;
+                    *reinterpret_cast<x3h4*>(tw + 32) = tl;
                 }
                 if (!p.out) continue;
             }

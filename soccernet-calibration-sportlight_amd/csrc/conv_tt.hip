@@ -35,6 +35,7 @@
 // 2 x 256 teams on the host (conv_tt_plan in hrnet.cpp): contiguous slices per XCD, longest-processing-time first.
 #include "common.hpp"
 #include "conv_tt.hpp"
+#include "x3.hpp"
 #include <cstddef>
 
 namespace sncal {

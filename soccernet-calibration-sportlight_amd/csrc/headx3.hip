@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "head.hpp"
 #include "softmax_px.hpp"
+#include "x3.hpp"
 #include <cstdio>
 #include <cstdlib>
 
@@ -24,7 +25,7 @@
 
 namespace sncal {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef x3h8 bf16x8;            // (x3.hpp: the 16-bit type of the split, fp16 or bf16; the name is historical)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -36,12 +37,12 @@ constexpr int OFF_B0 = OFF_W1L + RB * 2 * 1024, X_LDS = OFF_B0 + 1024;      // 5
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+    for (int e = 0; e < 8; ++e) X3_SPLIT(v[e], h[e], l[e]);
 }
 __device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    acc = X3_MFMA_32x32x16(al, bh, acc);
+    acc = X3_MFMA_32x32x16(ah, bl, acc);
+    return X3_MFMA_32x32x16(ah, bh, acc);
 }
 }  // namespace
 

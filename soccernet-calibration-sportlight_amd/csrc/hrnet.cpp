@@ -19,6 +19,7 @@
 #include "head.hpp"
 #include "bblock.hpp"
 #include "bblockx3.hpp"
+#include "x3.hpp"
 #include "conv_tt.hpp"
 
 #include <algorithm>
@@ -567,8 +568,9 @@ int pack_layer(sncal_hrnet& net, ConvLayer& L) {
                             if (ci >= L.cin) continue;
                             const float v = L.w[(((size_t)co * L.cin + ci) * KS + tap / KS) * KS + tap % KS] * L.scale[co];
                             if (net.dtype == SNCAL_BF16) { const uint16_t b = f2bf(v); memcpy(dst + e * 2, &b, 2); }
-                            else if (net.x3_generic) {          // [4 hi | 4 lo]: hi = bf16(w), lo = bf16(w - hi)
-                                const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+                            else if (net.x3_generic) {          // [4 hi | 4 lo]: hi = rne16(w), lo = rne16(w - hi) (x3.hpp)
+                                uint16_t h, l;
+                                x3_split_host(v, &h, &l);
                                 memcpy(dst + e * 2, &h, 2); memcpy(dst + 8 + e * 2, &l, 2);
                             }
                             else memcpy(dst + e * 4, &v, 4);
@@ -625,8 +627,7 @@ int pack_layer_x3(sncal_hrnet& net, ConvLayer& L) {
                         for (int e = 0; e < 8; ++e) {
                             const int ci = c * 16 + (lane >> 5) * 8 + e;
                             const float w = L.w[(((size_t)co * L.cin + ci) * 3 + s / 3) * 3 + s % 3] * L.scale[co];
-                            hi[e] = f2bf(w);
-                            lo[e] = f2bf(w - bf2f(hi[e]));
+                            x3_split_host(w, &hi[e], &lo[e]);
                         }
                     }
     SNCAL_CHECK_HIP(hipMalloc(&L.d_w_x3, host.size() * 2));
@@ -639,7 +640,7 @@ int pack_layer_bbx3(sncal_hrnet& net, ConvLayer& L) {
     if (L.d_w_bbx) { (void)hipFree(L.d_w_bbx); L.d_w_bbx = nullptr; }
     if (!x3_shape_ok(net, L) || L.cin != 48 || L.cout != 48) return SNCAL_OK;
     std::vector<uint16_t> host;
-    bbx3_pack_weights(L.w.data(), L.scale.data(), [](float v, uint16_t* hi, uint16_t* lo) { *hi = f2bf(v); *lo = f2bf(v - bf2f(*hi)); }, host);
+    bbx3_pack_weights(L.w.data(), L.scale.data(), [](float v, uint16_t* hi, uint16_t* lo) { x3_split_host(v, hi, lo); }, host);
     SNCAL_CHECK_HIP(hipMalloc(&L.d_w_bbx, host.size() * 2));
     SNCAL_CHECK_HIP(hipMemcpy(L.d_w_bbx, host.data(), host.size() * 2, hipMemcpyHostToDevice));
     return SNCAL_OK;
@@ -768,7 +769,7 @@ int pack_head(sncal_hrnet& net) {
         if (K1 % 16 == 0) {
             const int KS16 = K1 / 16, RB = (M2 * 16 + 31) / 32;
             std::vector<uint16_t> v0h((size_t)NQ * KS16 * 64 * 8, 0), v0l(v0h.size(), 0), v1h((size_t)NQ * RB * 2 * 64 * 8, 0), v1l(v1h.size(), 0);
-            auto put = [](float w, uint16_t& h, uint16_t& l) { h = f2bf(w); uint32_t u = (uint32_t)h << 16; float hf; memcpy(&hf, &u, 4); l = f2bf(w - hf); };
+            auto put = [](float w, uint16_t& h, uint16_t& l) { x3_split_host(w, &h, &l); };
             for (int q = 0; q < NQ; ++q)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int row = h32_row_channel(lane & 31), kb = (lane >> 5) * 8;
@@ -1093,7 +1094,7 @@ void conv_profile_entry(sncal_hrnet& net, const Op& op, int sb, const ConvVarian
     const ConvLayer& L = net.layers[op.conv];
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
-    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : net.x3_generic ? "bf16x3" : "f32", L.k, L.stride, bestv ? bestv->ni : 0, L.mi, L.g);
+    net.last_kernel = fmt("conv<%s,k%d,s%d,NI%d,MI%d,G%d>", net.dtype == SNCAL_BF16 ? "bf16" : net.x3_generic ? SNCAL_X3_NAME : "f32", L.k, L.stride, bestv ? bestv->ni : 0, L.mi, L.g);
     static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per layer shape
     if (detail) net.last_kernel += fmt("@%dx%d:%d->%d%s", to.H, to.W, L.cin, L.cout, op.res >= 0 ? "+res" : "");
     const double px = (double)sb * to.H * to.W;
@@ -1332,7 +1333,9 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<bf16x3,k3,s1,12x32x64>" : x3 ? "conv_tt<bf16x3,k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,12x32x64>" : x3 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per launch kind
+        if (detail) net.last_kernel += fmt("@%d members%s%s%s", n, tp.m[0].res ? "+res" : "", tp.m[0].out ? "+f32" : "", tp.m[0].out8 ? "+twin" : "");
     }
     return SNCAL_OK;
 }

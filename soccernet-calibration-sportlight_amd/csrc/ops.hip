@@ -8,6 +8,7 @@
 //                     (hrnet.py:329, line/hrnet.py:101)
 // All are HBM-bound streaming kernels: one 16-byte vector per lane, grid-stride.
 #include "common.hpp"
+#include "x3.hpp"
 #include <algorithm>
 #include "ops.hpp"
 #include "softmax_px.hpp"
@@ -152,13 +153,12 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
         for (int e = 0; e < GE; ++e) o[e] = (T)(p.relu ? fmaxf(acc[e], 0.f) : acc[e]);
         if constexpr (GE == 4) {
             if (p.out_twin) {          // bf16x3: hi = bf16(y), lo = bf16(y - hi) for the two-team convolution that reads this sum
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
-                bf4 th, tl;
+                x3h4 th, tl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { th[e] = (__bf16)(float)o[e]; tl[e] = (__bf16)((float)o[e] - (float)th[e]); }
+                for (int e = 0; e < 4; ++e) X3_SPLIT((float)o[e], th[e], tl[e]);
                 char* const tw = reinterpret_cast<char*>(p.out_twin) + (pix * p.C + (c0 & ~15)) * 4 + (c0 & 15) * 2;
-                *reinterpret_cast<bf4*>(tw) = th;
-                *reinterpret_cast<bf4*>(tw + 32) = tl;
+                *reinterpret_cast<x3h4*>(tw) = th;
+                *reinterpret_cast<x3h4*>(tw + 32) = tl;
             }
             if (!p.out) continue;
         }

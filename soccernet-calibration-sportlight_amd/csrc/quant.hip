@@ -7,6 +7,7 @@
 // The reference has no reduced-precision path (predict() is fp32: src/models/hrnet/metamodel.py:127-134); this is the
 // build's own C5 arithmetic, judged by the tolerance sweep against the fp32 engine (tests/test_fp8_gpu.py).
 #include "common.hpp"
+#include "x3.hpp"
 #include "ops.hpp"
 
 namespace sncal {
@@ -47,15 +48,15 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16x8* __restr
     }
 }
 
-// fp32 [N][H][W][C] -> split twin for the bf16x3 convolutions (conv_tt.hip MODE 2): per pixel and 16-channel group [16 hi | 16 lo] bf16
-// with hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-17 relative).  One thread = 8 channels: 32 B read, 16 B + 16 B written.
-__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, bf16x8* __restrict__ y, size_t n8) {
+// fp32 [N][H][W][C] -> split twin for the split-arithmetic convolutions (conv_tt.hip MODE 2): per pixel and 16-channel group
+// [16 hi | 16 lo] 16-bit codes with hi = rne16(x), lo = rne16(x - hi) (x3.hpp).  One thread = 8 channels: 32 B read, 16 B + 16 B written.
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, x3h8* __restrict__ y, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         const float4 a = x[2 * i], b = x[2 * i + 1];
         const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        bf16x8 h, l;
+        x3h8 h, l;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { h[e] = (__bf16)f[e]; l[e] = (__bf16)(f[e] - (float)h[e]); }
+        for (int e = 0; e < 8; ++e) X3_SPLIT(f[e], h[e], l[e]);
         const size_t g16 = i >> 1, half = i & 1;            // 16-channel group, which 8 of its channels
         y[g16 * 4 + half] = h;
         y[g16 * 4 + 2 + half] = l;
@@ -66,7 +67,7 @@ int launch_split_f32(const void* x, void* y, size_t n, hipStream_t s) {
     if (n % 16) { set_error("split: element count %zu is not a multiple of 16", n); return SNCAL_ERR_ARG; }
     const size_t n8 = n / 8;
     const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 4096);
-    SNCAL_LAUNCH(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<bf16x8*>(y), n8);
+    SNCAL_LAUNCH(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<x3h8*>(y), n8);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

@@ -1,0 +1,74 @@
+// The 16-bit type of the split (x3) arithmetic: every fp32 operand x = hi + lo, hi = rne16(x), lo = rne16(x - hi), every product
+// w.x = w_hi.x_hi + w_hi.x_lo + w_lo.x_hi on the 16-bit matrix pipe with fp32 accumulation.
+//   SNCAL_X3_F16 = 1 (default since round 4): hi and lo are IEEE fp16 -- 11 + 11 significand bits, the dropped lo.lo term is ~2^-22 of a
+//     product; v_mfma_*_f16 keeps fp16 subnormals and accumulates exactly (tools/dev/f16_mfma_probe.hip), so small operands lose
+//     precision gracefully (|x| < 2^-3: lo is subnormal, absolute error <= 2^-25) and nothing needs scaling; |x| is clamped to the
+//     fp16 range (65504: a network whose activations leave it has left any sane operating point);
+//   SNCAL_X3_F16 = 0: bf16 -- 8 + 8 bits, dropped term ~2^-16, fp32's exponent range (rounds 3's engine, `bf16x3`).
+// Same instruction rate, same bytes: the two differ in the conversions only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+
+#ifndef SNCAL_X3_F16
+#define SNCAL_X3_F16 1
+#endif
+
+namespace sncal {
+
+#if SNCAL_X3_F16
+typedef _Float16 x3h;
+#define SNCAL_X3_NAME "fp16x3"
+#define X3_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define X3_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 x3h;
+#define SNCAL_X3_NAME "bf16x3"
+#define X3_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define X3_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) x3h x3h8;
+typedef __attribute__((ext_vector_type(4))) x3h x3h4;
+
+// split: hi = rne16(v), lo = rne16(v - hi).  fp16: |v| is clamped to the format's range FIRST -- a stale or padded operand far outside it
+// (it meets a zero weight, e.g. a gather lane outside its box) must stay finite in BOTH parts: with only hi clamped, lo = v - 65504
+// converted to +inf and inf x 0 poisoned the sum (found by the batch-independence test: the poison depends on what the workspace held).
+__device__ __forceinline__ float x3_clamp(float v) {
+#if SNCAL_X3_F16
+    return __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+#else
+    return v;
+#endif
+}
+// (a macro: vector elements do not bind to references)
+#define X3_SPLIT(v, hi, lo) do { const float x3v_ = ::sncal::x3_clamp(v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
+
+// host side (weight packing): the same two codes
+inline uint16_t x3_code_host(float v) {
+#if SNCAL_X3_F16
+    v = v > 65504.f ? 65504.f : v < -65504.f ? -65504.f : v;
+    const _Float16 h = (_Float16)v;
+    uint16_t c; memcpy(&c, &h, 2); return c;
+#else
+    uint32_t u; memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+#endif
+}
+inline float x3_value_host(uint16_t c) {
+#if SNCAL_X3_F16
+    _Float16 h; memcpy(&h, &c, 2); return (float)h;
+#else
+    const uint32_t u = (uint32_t)c << 16; float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+inline void x3_split_host(float v, uint16_t* hi, uint16_t* lo) {
+#if SNCAL_X3_F16
+    v = v > 65504.f ? 65504.f : v < -65504.f ? -65504.f : v;
+#endif
+    *hi = x3_code_host(v); *lo = x3_code_host(v - x3_value_host(*hi));
+}
+
+}  // namespace sncal

@@ -19,7 +19,9 @@ from . import _lib
 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs')
 BN_EPS = 1e-5
-DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2, 'e4m3': 2, 'bf16x3': 3, 'x3': 3}
+# 'fp16x3' / 'bf16x3': the split-arithmetic (fp32-class) engine; a given libsncal.so implements ONE of the two 16-bit split types
+# (sncal_x3_name(): fp16 since round 4, bf16 with -DSNCAL_X3_F16=0) and refuses the other name; 'x3' takes whichever the build has
+DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2, 'e4m3': 2, 'fp16x3': 3, 'bf16x3': 3, 'x3': 3}
 
 
 def _plain(obj):
@@ -101,6 +103,9 @@ class HRNetHeatmap:
         self.dtype = DTYPES[dtype]
         self.device = torch.device(device)
         self._L = _lib.lib()
+        if dtype in ('fp16x3', 'bf16x3') and dtype != self._L.sncal_x3_name().decode():
+            raise _lib.SncalError(f"dtype {dtype!r}: this libsncal.so implements the split-arithmetic engine as "
+                                  f"{self._L.sncal_x3_name().decode()!r} (rebuild with -DSNCAL_X3_F16={int(dtype == 'fp16x3')} for the other split type)")
         self._h = _lib.vp()
         desc = _desc(self.cfg)
         _lib.check(self._L.sncal_hrnet_create(ctypes.byref(desc), self.dtype, ctypes.byref(self._h)), 'sncal_hrnet_create')

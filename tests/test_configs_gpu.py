@@ -38,7 +38,7 @@ def test_c2_w32_480x270_batch32_decode(sncal, cuda):
     assert db.mean() < 0.12 and db.max() < 1.0
     # the fp32-class engine (every branch width of W32 on the 64 x 12 x 32 two-team tile, stem-interpolation head on the generic
     # split-arithmetic kernels): oracle indices, log-probabilities to 1e-3
-    net3 = sncal.HRNetHeatmap('hrnet_w32', dtype='bf16x3', device=cuda)
+    net3 = sncal.HRNetHeatmap('hrnet_w32', dtype='fp16x3', device=cuda)
     net3.load_state_dict(sd)
     h3, k3 = net3.forward(x.to(cuda), want_heat=True, decode_size=(540, 960))
     assert np.abs(h3[:2].cpu().numpy() - ref).max() <= 1e-3
@@ -128,7 +128,7 @@ def test_c5_w48_1080p_flagship(sncal, cuda):
     assert d.mean() < 0.12 and d.max() < 1.0, (d.mean(), d.max())
     del h16, net16
     torch.cuda.empty_cache()
-    net3 = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16x3', device=cuda)          # the fp32-class engine at C5's shapes: oracle indices
+    net3 = sncal.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=cuda)          # the fp32-class engine at C5's shapes: oracle indices
     net3.load_state_dict(sd)
     h3, k3 = net3.forward(x[:1].to(cuda), want_heat=True, decode_size=(1080, 1920))
     assert np.abs(h3.cpu().numpy() - ref).max() <= 1e-3
@@ -220,9 +220,9 @@ def test_c4_per_gpu_share_batch64_w48_keypoint_and_line_networks(sncal, cuda):
     sd_l = bench.seeded_weights('line_hrnet_w48', seed=2)
     frames, expect = sncal.synth.stamped_frames(B, seed=91)
     x = torch.from_numpy(frames).to(cuda)
-    knet = sncal.HRNetHeatmap('hrnet_w48', dtype='bf16x3', device=cuda)
+    knet = sncal.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=cuda)
     knet.load_state_dict(sd_k)
-    lnet = sncal.HRNetHeatmap('line_hrnet_w48', dtype='bf16x3', device=cuda)
+    lnet = sncal.HRNetHeatmap('line_hrnet_w48', dtype='fp16x3', device=cuda)
     lnet.load_state_dict(sd_l)
     cc = sncal.CameraCreator(sncal.PITCH_POINTS, **bench.SOLVER_KW)
     pipe = sncal.CalibrationPipeline(knet, cc, line_net=lnet, line_sigma=3.0, line_scale=4, line_prob_thre=0.0)
@@ -249,7 +249,7 @@ def test_c4_per_gpu_share_batch64_w48_keypoint_and_line_networks(sncal, cuda):
     assert float(near[vis & (kp.cpu().numpy()[..., 2] >= 0.2)].mean()) >= 0.98
 
 
-@pytest.mark.parametrize('dtype', ['bf16x3', 'fp8'])
+@pytest.mark.parametrize('dtype', ['fp16x3', 'fp8'])
 def test_c5_per_gpu_share_batch128_w48_1080p(sncal, cuda, dtype):
     """C5 at its per-GPU share (1024 frames over 8 GPUs = 128 frames per GPU): HRNet-W48 on 128 frames of 1920x1080 (two sub-batches
     of 64), fp32-class engine and e4m3 engine.  Size-independent property: a frame's decoded keypoints do not depend on the batch it
@@ -271,6 +271,6 @@ def test_c5_per_gpu_share_batch128_w48_1080p(sncal, cuda, dtype):
     sel = [0, 63, 64, 127]                                                                # both sub-batches, their edges
     _, kps = net.forward(x[sel].contiguous(), want_heat=False, decode_size=(1080, 1920))
     assert torch.equal(kps, kp[sel])
-    if dtype == 'bf16x3':
+    if dtype == 'fp16x3':
         ref = hr.forward(sd, x[:1].cpu(), cfg).numpy()
         assert np.array_equal(kp[:1].cpu().numpy()[..., :2], od.keypoint_decode(ref, (1080, 1920))[..., :2])

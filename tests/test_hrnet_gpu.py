@@ -46,22 +46,22 @@ def test_keypoint_net_fp32_matches_reference(sncal, cuda, gold_dir, name, cfgn):
     assert np.array_equal(kp, od.keypoint_decode(heat, (540, 960)))       # fused decode == oracle decode
 
 
-def test_keypoint_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
-    """The fp32-class engine (split-bf16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4, fp32 everywhere else) against the
+def test_keypoint_net_fp16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
+    """The fp32-class engine (split-fp16 arithmetic in the 3x3 stride-1 convolutions of stages 2-4, fp32 everywhere else) against the
     SAME reference capture as the exact-fp32 engine: bit-identical indices, confidences to 3e-5, log-probabilities (down to -52) to
-    6e-4.  Measured on this golden: exact-fp32 engine 4.6e-5 max / 8.7e-6 mean (confidences 3.4e-6); bf16x3 3.8e-4 max / 5.7e-5 mean
+    6e-4.  Measured on this golden: exact-fp32 engine 4.6e-5 max / 8.7e-6 mean (confidences 3.4e-6); fp16x3 3.8e-4 max / 5.7e-5 mean
     (confidences 1.2e-5) with the fused split-arithmetic head, 2.2e-4 / 3.9e-5 with the head on the exact kernels (SNCAL_HEADX3=0)."""
-    g, heat, kp = _run(sncal, cuda, gold_dir, 'hrnet_w48_540x960', 'hrnet_w48', 'bf16x3')
+    g, heat, kp = _run(sncal, cuda, gold_dir, 'hrnet_w48_540x960', 'hrnet_w48', 'fp16x3')
     assert _err(g, heat) <= 6e-4
     assert np.array_equal(kp[..., :2], g['decode'][..., :2])
     assert np.abs(kp[..., 2] - g['decode'][..., 2]).max() <= 3e-5
     assert np.array_equal(kp, od.keypoint_decode(heat, (540, 960)))
 
 
-def test_line_net_bf16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
+def test_line_net_fp16x3_matches_reference_at_the_fp32_tolerance(sncal, cuda, gold_dir):
     """Line net on the fp32-class engine: sigmoid heatmaps to 1e-4 of the reference capture (measured 5.2e-5 with every convolution in
-    split-bf16 arithmetic, below 2e-5 with only the 3x3 stride-1 ones: SNCAL_X3_GENERIC=0), EHM decode indices identical."""
-    g, heat, _ = _run(sncal, cuda, gold_dir, 'line_w48_540x960', 'line_hrnet_w48', 'bf16x3', line=True)
+    split-fp16 arithmetic, below 2e-5 with only the 3x3 stride-1 ones: SNCAL_X3_GENERIC=0), EHM decode indices identical."""
+    g, heat, _ = _run(sncal, cuda, gold_dir, 'line_w48_540x960', 'line_hrnet_w48', 'fp16x3', line=True)
     assert _err(g, heat) <= 1e-4
     dec = sncal.EHMPredictionTransform(scale=4, sigma=3)(torch.from_numpy(heat).to(cuda)).cpu().numpy()
     assert np.array_equal(dec[..., :2], g['decode'][..., :2])
@@ -87,7 +87,7 @@ def test_line_net_matches_reference(sncal, cuda, gold_dir, name, cfgn, dtype, to
         assert np.array_equal(dec[..., :2], g['decode'][..., :2])
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16x3'])
 def test_batch_and_subbatch_consistency(sncal, cuda, dtype):
     """Frames are independent: a batch of 11 (sub-batches 8 + 3) equals per-frame results bit-for-bit."""
     cfg = hr.load_config('hrnet_w18')
@@ -249,7 +249,7 @@ def test_two_team_conv_kernel_matches_the_generic_kernel(sncal, cuda, monkeypatc
     assert float((kps[0][..., :2] == kps[1][..., :2]).all(-1).float().mean()) >= 0.9
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16x3'])
 def test_frames_are_independent_of_batch_size_and_position(sncal, cuda, dtype):
     """Size-independent property at the bench configuration (W48, 960x540, both fast engines): a frame's keypoints and heatmap do not
     depend on the batch it travels in -- different batch sizes pick different tile shapes, grid orders and grouped

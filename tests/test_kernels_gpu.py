@@ -31,6 +31,9 @@ BN_EPS = 1e-5
 
 
 # ---- reference-side weights: the fold of hrnet.py's load_state_dict, restated (fp64 fold, fp32 storage) ---------------------
+X3_T = torch.float16          # 16-bit type of the split twins: the build's (sncal_x3_name()); set by the `sncal` fixture user below
+
+
 def folded(sd, name, bn, has_bias):
     w = sd[name + '.weight'].to(torch.float64)
     cout = w.shape[0]
@@ -160,6 +163,8 @@ E4M3_ULP = 2.0 ** -3
 
 def run_case(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, want_heat=True):
     """One forward with every op tapped; returns (ops, tensors dict (op idx, tensor id) -> torch tensor, net)."""
+    global X3_T
+    X3_T = torch.float16 if sncal._lib.lib().sncal_x3_name() == b'fp16x3' else torch.bfloat16
     net = sncal.HRNetHeatmap(cfg, dtype=dtype, device=cuda)
     net.load_state_dict(sd)
     if dtype == 'fp8':
@@ -192,7 +197,7 @@ def run_case(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, want_heat=True):
 def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
     ops, taps, net = run_case(sncal, cuda, cfg, sd, x, dtype, fp8_layers)
     W = Weights(net, sd, cuda)
-    f32_engine = dtype in ('fp32', 'bf16x3')
+    f32_engine = dtype in ('fp32', 'fp16x3')
     act_round = (lambda t: t) if f32_engine else bf16r
     rel_out = 1e-5 if f32_engine else BF16_ULP
     abs_out = 2e-4 if f32_engine else 1e-3
@@ -236,7 +241,7 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 check(op['name'] + ' + conv2', got, ref, rel_out, 4e-3, stats, 'bblock48_fused')
                 continue
             if label == 'bblockx3_fused' and op['kernel'] == 'bblockx3_fused':
-                # bf16x3, fused 48-channel BasicBlock (bblockx3.hip): x (split twin) -> conv1 + shift, ReLU -> mid (split in LDS, never in
+                # fp16x3, fused 48-channel BasicBlock (bblockx3.hip): x (split twin) -> conv1 + shift, ReLU -> mid (split in LDS, never in
                 # HBM) -> conv2 + shift + x, ReLU -> split twin and / or fp32.  Every product good to ~2^-16: 3e-5 of sum |x w| per
                 # convolution, the first one's bound carried through |w2|
                 nxt = by_idx[op['idx'] + 1]
@@ -274,29 +279,29 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                 # layers: up to 1.5e-4 = 2^-12.7 of sum |x w|; allowed: 2^-11 of it (a wrong tap moves the sum by ~2^-6 of it)
                 fp8_slack = 2.0 ** -11 * conv_ref(xin.abs(), wq.abs(), 1) * oscale[None, :, None, None]
             elif op.get('x3'):
-                # bf16x3: fp32 operands split into bf16 hi + lo, hi.hi + hi.lo + lo.hi in fp32: every product is good to ~2^-16 of
+                # fp16x3: fp32 operands split into bf16 hi + lo, hi.hi + hi.lo + lo.hi in fp32: every product is good to ~2^-16 of
                 # itself, so the sum is good to a few 1e-5 of sum |x w| (measured below 1e-5); a wrong tap is 2^-6 of it
                 raw = T(op, ti['twin'])                       # the operand the kernel reads: the split twin, hi + lo = x to 2^-17
-                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                pr = raw.view(X3_T).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
                 xin = (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2).contiguous()
                 y = conv_ref(xin, w, op['stride']) + shift[None, :, None, None]
                 fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride'])
             else:
                 xin = nchw(T(op, op['in']))[:, :op['cin']]
                 y = conv_ref(xin, act_round(w), op['stride']) + shift[None, :, None, None]
-                # bf16x3 engine, generic kernel (x3_t): fp32 operands split in registers, same arithmetic and the same bound as above
+                # fp16x3 engine, generic kernel (x3_t): fp32 operands split in registers, same arithmetic and the same bound as above
                 fp8_slack = 3e-5 * conv_ref(xin.abs(), w.abs(), op['stride']) if op.get('x3g') else 0.0
             if op['res'] >= 0 and op.get('res_twin'):
-                # bf16x3, inside a BasicBlock chain: the block input lives only as the split twin its first convolution read
+                # fp16x3, inside a BasicBlock chain: the block input lives only as the split twin its first convolution read
                 raw = T(op, net.plan_tensor(op['res'])['twin'])
-                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                pr = raw.view(X3_T).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
                 y = y + (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
             elif op['res'] >= 0:
                 y = y + nchw(T(op, op['res']))[:, op['out_coff']:op['out_coff'] + op['cout']]
             if op['relu']:
                 y = torch.relu(y)
             to = net.plan_tensor(op['out'])
-            kern = 'conv_tt<fp8,k3,s1,8x32x96>' if op['fp8'] else ('conv_tt<bf16x3,k3,s1,12x32x64>' if op['cout'] % 96 else 'conv_tt<bf16x3,k3,s1,8x32x96>') if op.get('x3') else label
+            kern = 'conv_tt<fp8,k3,s1,8x32x96>' if op['fp8'] else ('conv_tt<fp16x3,k3,s1,12x32x64>' if op['cout'] % 96 else 'conv_tt<fp16x3,k3,s1,8x32x96>') if op.get('x3') else label
             name = f"{op['name']} {to['H']}x{to['W']} {op['cin']}->{op['cout']}" + ('+res' if op['res'] >= 0 else '')
             checked = False
             gen_twin = bool(op.get('x3g')) and _producer_twin(net, op, taps)
@@ -313,7 +318,7 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             if op.get('x3') and to['twin'] >= 0 and net.plan_tensor(to['twin'])['alive'] and (op['idx'], to['twin']) in taps:
                 # split twin written by the epilogue: [16 hi | 16 lo] bf16 per 16-channel group; hi + lo reproduces y to 2^-17
                 raw = T(op, to['twin'])                                                  # fp32-typed storage, (N,H,W,C)
-                pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+                pr = raw.view(X3_T).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
                 got_t = (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
                 check(name + ' [split twin out]', got_t, y, 1e-5 + 2.0 ** -16, abs_out + fp8_slack, stats, kern + ' split out')
                 checked = True
@@ -339,8 +344,8 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
             if op['relu']:
                 acc = torch.relu(acc)
             nm = f"fuse sum -> {to['H']}x{to['W']}x{C0} ({len(op['src'])} sources)"
-            tw = dtype == 'bf16x3' and _producer_twin(net, op, taps)
-            if tw:          # bf16x3: the sum's split twin for the two-team convolution that reads it; the fp32 form only if somebody reads that
+            tw = dtype == 'fp16x3' and _producer_twin(net, op, taps)
+            if tw:          # fp16x3: the sum's split twin for the two-team convolution that reads it; the fp32 form only if somebody reads that
                 check(nm + ' [split twin out]', _split_twin_value(T(op, to['twin'])).permute(0, 2, 3, 1), acc, 1e-5 + 2.0 ** -16, abs_out, stats, 'upsample_add split out')
             if not tw or _bf16_written(net, ops, op):
                 got = T(op, op['out']).to(torch.float32)[..., op['out_coff']:op['out_coff'] + C0]
@@ -361,12 +366,12 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
 
 def _split_twin_value(raw):
     """(N,H,W,C) fp32-typed storage of a split twin -> (N,C,H,W) fp32: hi + lo."""
-    pr = raw.view(torch.bfloat16).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
+    pr = raw.view(X3_T).reshape(raw.shape[0], raw.shape[1], raw.shape[2], raw.shape[3] // 16, 2, 16).to(torch.float32)
     return (pr[..., 0, :] + pr[..., 1, :]).reshape(raw.shape).permute(0, 3, 1, 2)
 
 
 def _producer_twin(net, op, taps):
-    """bf16x3: does this generic convolution / fuse sum write the split twin of its (dense) output?  (hrnet.cpp producer_twin)"""
+    """fp16x3: does this generic convolution / fuse sum write the split twin of its (dense) output?  (hrnet.cpp producer_twin)"""
     to = net.plan_tensor(op['out'])
     if to['twin'] < 0 or not net.plan_tensor(to['twin'])['alive'] or (op['idx'], to['twin']) not in taps:
         return False
@@ -393,7 +398,7 @@ def head_reference(net, op, T, W, by_idx, stats, dev, exact=False):
     weights, bf16 hidden vector)."""
     to = net.plan_tensor(op['out'])
     H, Wd = to['H'], to['W']
-    rnd = (lambda t: t) if exact else bf16r          # bf16x3 engine (headx3.hip): fp32 operands, every product good to ~2^-16
+    rnd = (lambda t: t) if exact else bf16r          # fp16x3 engine (headx3.hip): fp32 operands, every product good to ~2^-16
     direct = T(op, op['head_direct']).to(torch.float32)                    # (N,H,W,Cd)
     parts = [direct]
     for f in op['head_fold']:
@@ -417,7 +422,7 @@ def head_reference(net, op, T, W, by_idx, stats, dev, exact=False):
     ref = ref.reshape(kin.shape[0], H, Wd, cout1)
     got = T(op, op['out'])[..., :cout1]
     if exact:
-        check(f'head -> logits {H}x{Wd} (split-bf16)', got, ref, 1e-4, 5e-4, stats, 'headx3_fused')
+        check(f'head -> logits {H}x{Wd} (split-fp16)', got, ref, 1e-4, 5e-4, stats, 'headx3_fused')
         return
     # the hidden vector is rounded to bf16 BEFORE the 784-term second product: a hidden value whose fp32 sums differ in the last bits
     # between kernel and reference rounds to the other neighbour (one bf16 ulp of that hidden unit x |w1|).  Per element: up to eight
@@ -518,52 +523,52 @@ def test_every_launch_of_the_fp32_engine_w18(sncal, cuda):
     assert any(k.startswith('conv<f32') for k in stats)
 
 
-def test_every_launch_of_the_bf16x3_engine_w48_540p(sncal, cuda):
+def test_every_launch_of_the_fp16x3_engine_w48_540p(sncal, cuda):
     """The fp32-class engine: fp32 tensors everywhere, the 3x3 stride-1 convolutions of stages 2-4 (wide branches and the 48-channel
-    branch as fused BasicBlocks, bblockx3.hip) in split-bf16 arithmetic -- each against torch fp32 on the
+    branch as fused BasicBlocks, bblockx3.hip) in split-fp16 arithmetic -- each against torch fp32 on the
     split twin it reads (hi + lo; written by the producing convolution's epilogue or by split_f32_kernel), its fp32 output and the
     split twin it hands on."""
     sd = _weights('hrnet_w48')
-    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'bf16x3', tag='w48 540p bf16x3')
-    _report(stats, 'bf16x3_w48_540p')
-    k, kb = 'conv_tt<bf16x3,k3,s1,8x32x96>', 'bblockx3_fused'   # 144 wide convolutions + 32 fused 48-channel blocks, each checked on its fp32 output, its twin, or both
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'fp16x3', tag='w48 540p fp16x3')
+    _report(stats, 'fp16x3_w48_540p')
+    k, kb = 'conv_tt<fp16x3,k3,s1,8x32x96>', 'bblockx3_fused'   # 144 wide convolutions + 32 fused 48-channel blocks, each checked on its fp32 output, its twin, or both
     n = lambda key: stats.get(key, {'ops': 0})['ops']
     assert n(k) >= 12 and n(k + ' split out') >= 120                                         # (fp32 outputs: module ends only)
     assert n(k) + n(k + ' split out') >= 144 and n(kb) + n(kb + ' split out') >= 32 and n(kb) >= 8 and n(kb + ' split out') >= 24
 
 
-def test_every_launch_of_the_bf16x3_engine_w32_270p(sncal, cuda):
+def test_every_launch_of_the_fp16x3_engine_w32_270p(sncal, cuda):
     """BASELINE config C2's shapes (HRNet-W32, 480x270): branch widths 32 / 64 / 128 / 256 all run as 64-channel blocks of the
     64 x 12 x 32 tile (the 32-channel branch half padded), maps 68x120 / 34x60 / 17x30 / 9x15 (a 9-row branch inside 12-row tiles)."""
     sd = _weights('hrnet_w32')
-    stats = verify_plan(sncal, cuda, 'hrnet_w32', sd, _frames(5, 270, 480, 19, cuda), 'bf16x3', tag='w32 270p bf16x3')
-    _report(stats, 'bf16x3_w32_270p')
-    k48 = 'conv_tt<bf16x3,k3,s1,12x32x64>'
+    stats = verify_plan(sncal, cuda, 'hrnet_w32', sd, _frames(5, 270, 480, 19, cuda), 'fp16x3', tag='w32 270p fp16x3')
+    _report(stats, 'fp16x3_w32_270p')
+    k48 = 'conv_tt<fp16x3,k3,s1,12x32x64>'
     n = lambda key: stats.get(key, {'ops': 0})['ops']
     assert n(k48) + n(k48 + ' split out') >= 200, {k: v['ops'] for k, v in stats.items()}
-    assert any(k.startswith('conv<bf16x3,k3,s2') for k in stats) and any(k.startswith('conv<bf16x3,k1,s1') for k in stats)
+    assert any(k.startswith('conv<fp16x3,k3,s2') for k in stats) and any(k.startswith('conv<fp16x3,k1,s1') for k in stats)
 
 
-def test_every_launch_of_the_bf16x3_engine_w48_1080p_and_odd_sizes(sncal, cuda):
+def test_every_launch_of_the_fp16x3_engine_w48_1080p_and_odd_sizes(sncal, cuda):
     """C5's shapes (2 frames of 1920x1080) and a 270x500 input (68x125 / 34x63 / 17x32 / 9x16 maps, stem-interpolation head path)."""
     sd = _weights('hrnet_w48')
-    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(2, 1080, 1920, 20, cuda), 'bf16x3', tag='w48 1080p bf16x3')
-    _report(stats, 'bf16x3_w48_1080p')
-    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24 and stats['bblockx3_fused']['ops'] >= 8
-    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(5, 270, 500, 21, cuda), 'bf16x3', tag='w48 270x500 bf16x3')
-    _report(stats, 'bf16x3_w48_270x500')
-    assert 'conv_tt<bf16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(2, 1080, 1920, 20, cuda), 'fp16x3', tag='w48 1080p fp16x3')
+    _report(stats, 'fp16x3_w48_1080p')
+    assert 'conv_tt<fp16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24 and stats['bblockx3_fused']['ops'] >= 8
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(5, 270, 500, 21, cuda), 'fp16x3', tag='w48 270x500 fp16x3')
+    _report(stats, 'fp16x3_w48_270x500')
+    assert 'conv_tt<fp16x3,k3,s1,8x32x96> split out' in stats and stats['bblockx3_fused split out']['ops'] >= 24
 
 
-def test_every_launch_of_the_bf16x3_engine_w18_and_line_net(sncal, cuda):
+def test_every_launch_of_the_fp16x3_engine_w18_and_line_net(sncal, cuda):
     """W18 (18 / 36 / 72 / 144 channels: no two-team tiles, every convolution on the generic split-arithmetic kernel) and the line
     network's head configuration."""
     from oracle import hrnet_ref as hr
     cfg = hr.load_config('hrnet_w18')
     sd = hr.seeded_state_dict(cfg, 3, 4.0)
-    stats = verify_plan(sncal, cuda, 'hrnet_w18', sd, _frames(3, 135, 240, 22, cuda), 'bf16x3', tag='w18 135x240 bf16x3')
-    _report(stats, 'bf16x3_w18_135x240')
-    assert any(k.startswith('conv<bf16x3') for k in stats)
+    stats = verify_plan(sncal, cuda, 'hrnet_w18', sd, _frames(3, 135, 240, 22, cuda), 'fp16x3', tag='w18 135x240 fp16x3')
+    _report(stats, 'fp16x3_w18_135x240')
+    assert any(k.startswith('conv<fp16x3') for k in stats)
     sd = _weights('line_hrnet_w48')
-    stats = verify_plan(sncal, cuda, 'line_hrnet_w48', sd, _frames(2, 540, 960, 23, cuda), 'bf16x3', tag='line w48 540p bf16x3')
-    _report(stats, 'bf16x3_line_w48_540p')
+    stats = verify_plan(sncal, cuda, 'line_hrnet_w48', sd, _frames(2, 540, 960, 23, cuda), 'fp16x3', tag='line w48 540p fp16x3')
+    _report(stats, 'fp16x3_line_w48_540p')

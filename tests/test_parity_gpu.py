@@ -97,7 +97,7 @@ def parity_table(sncal, kp32, kpx, heat32, expect, cc):
 
 
 @pytest.mark.parametrize('row_gain', [0.1, 0.35, 0.7])
-@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'bf16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp16x3'])
 def test_engine_index_agreement_on_the_deep_path_workload(sncal, cuda, dtype, row_gain):
     key = ('sd', row_gain)
     if key not in _CACHE:
@@ -130,7 +130,7 @@ def test_engine_index_agreement_on_the_deep_path_workload(sncal, cuda, dtype, ro
         if row['gap_lo'] >= 0.2 and row['n']:      # measured: bf16 flips only below 0.1, fp8 below 0.2 (profiles/r03_parity_deep_*.json)
             assert row['agreement'] == 1.0, row
     assert summary['index_agreement_usable'] >= 0.9, summary
-    if dtype == 'bf16x3':                        # the fp32-class engine: every usable keypoint identical, every camera within the north star's 1e-4
+    if dtype == 'fp16x3':                        # the fp32-class engine: every usable keypoint identical, every camera within the north star's 1e-4
         assert summary['index_agreement_usable'] == 1.0 and summary['frames_with_identical_usable_indices'] == B, summary
         r = summary['rmse_rel_delta_all_frames']
         assert r['frames_le_1e-4'] == r['frames'], summary

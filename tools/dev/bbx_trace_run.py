@@ -1,4 +1,4 @@
-"""One bf16x3 W48 forward at the bench size with SNCAL_BBX_TRACE set (run on the GPU box), then tools/bbx_trace.py."""
+"""One fp16x3 W48 forward at the bench size with SNCAL_BBX_TRACE set (run on the GPU box), then tools/bbx_trace.py."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -6,7 +6,7 @@ os.environ.setdefault('SNCAL_BBX_TRACE', 'gpurun_out/bbx_trace.bin')
 import sncal_amd
 from bench import seeded_weights
 dev = torch.device('cuda:0')
-net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='bf16x3', device=dev)
+net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=dev)
 net.load_state_dict(seeded_weights('hrnet_w48', 1))
 x = torch.rand((int(sys.argv[1]) if len(sys.argv) > 1 else 64, 3, 540, 960), device=dev)
 for _ in range(2):

@@ -8,7 +8,7 @@ from bench import seeded_weights
 dev = torch.device('cuda:0')
 sd = seeded_weights('hrnet_w48', 1)
 rows = {}
-for dtype in ('fp32', 'bf16x3', 'bf16'):
+for dtype in ('fp32', 'fp16x3', 'bf16'):
     net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
     net.load_state_dict(sd)
     for B in (1, 2, 4, 8, 16, 32, 64):

@@ -16,7 +16,7 @@ sd = sncal_amd.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1)
 cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **bench.SOLVER_KW)
 res = {}
 kps = {}
-for dtype in ('fp32', 'bf16x3', 'bf16'):
+for dtype in ('fp32', 'fp16x3', 'bf16'):
     net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
     net.load_state_dict(sd)
     out = []
@@ -28,13 +28,14 @@ for dtype in ('fp32', 'bf16x3', 'bf16'):
     kps[dtype] = torch.cat(out, 0)
     del net
 recs = {d: cc.records(cc.solve_device(kps[d])) for d in kps}
-for d in ('bf16x3', 'bf16'):
+for d in ('fp16x3', 'bf16'):
     res[d] = bench.parity_of(kps['fp32'].cpu().numpy(), recs['fp32'], kps[d].cpu().numpy(), recs[d], 'exact-fp32 engine of this build')
     res[d]['row_gain'] = row_gain
     print(d, {k: res[d][k] for k in ('frames', 'usable_keypoints', 'moved_usable_keypoints', 'index_agreement', 'index_agreement_all_rows', 'cameras_both',
-                                     'frames_rmse_rel_delta_le_1e-4', 'rmse_rel_delta_max')})
-# the moved keypoints of bf16x3: how close was the decision in the exact-fp32 heatmap?  (top-1 minus the value at the cell bf16x3 chose, log-probability)
-k32, k3 = kps['fp32'].cpu().numpy(), kps['bf16x3'].cpu().numpy()
+                                     'frames_rmse_rel_delta_le_1e-4', 'rmse_rel_delta_max', 'conf_abs_delta_max_usable', 'conf_signed_delta_mean_usable',
+                                     'threshold_crossings')})
+# the moved keypoints of fp16x3: how close was the decision in the exact-fp32 heatmap?  (top-1 minus the value at the cell fp16x3 chose, log-probability)
+k32, k3 = kps['fp32'].cpu().numpy(), kps['fp16x3'].cpu().numpy()
 moved = np.argwhere((k32[..., 2] >= 0.2) & ((k32[..., :2] != k3[..., :2]).any(-1)))
 net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='fp32', device=dev)
 net.load_state_dict(sd)
@@ -49,12 +50,12 @@ for f, k in moved[:32]:
     c32 = (int(round(k32[f, k, 1] / sy)), int(round(k32[f, k, 0] / sx)))
     c3 = (int(round(k3[f, k, 1] / sy)), int(round(k3[f, k, 0] / sx)))
     c32 = (min(c32[0], h.shape[0] - 1), min(c32[1], h.shape[1] - 1)); c3 = (min(c3[0], h.shape[0] - 1), min(c3[1], h.shape[1] - 1))
-    gaps.append(dict(frame=int(f), keypoint=int(k), fp32_cell=c32, bf16x3_cell=c3, fp32_logp_at_fp32_cell=float(h[c32]), fp32_logp_at_bf16x3_cell=float(h[c3]),
+    gaps.append(dict(frame=int(f), keypoint=int(k), fp32_cell=c32, fp16x3_cell=c3, fp32_logp_at_fp32_cell=float(h[c32]), fp32_logp_at_fp16x3_cell=float(h[c3]),
                      gap=float(h.max() - h[c3]), conf=float(k32[f, k, 2])))
     print('moved', gaps[-1])
-res['bf16x3']['moved_keypoints_fp32_gap'] = gaps
+res['fp16x3']['moved_keypoints_fp32_gap'] = gaps
 # frames whose cameras differ although no usable index moved: does a confidence cross one of the solver's thresholds?
-r32, r3 = recs['fp32'], recs['bf16x3']
+r32, r3 = recs['fp32'], recs['fp16x3']
 odd = []
 for i in range(N):
     if r32[i].status == 0 or r3[i].status == 0 or r32[i].rmse <= 0:
@@ -68,8 +69,10 @@ for i in range(N):
              for th in (0.5, 0.35, 0.2) if (k32[i, k, 2] >= th) != (k3[i, k, 2] >= th)]
     other = [(int(k), float(k32[i, k, 0]), float(k32[i, k, 1]), float(k3[i, k, 0]), float(k3[i, k, 1])) for k in range(k32.shape[1])
              if (k32[i, k, :2] != k3[i, k, :2]).any()]
-    odd.append(dict(frame=i, rmse_fp32=float(r32[i].rmse), rmse_bf16x3=float(r3[i].rmse), threshold_crossings=cross, moved_unusable_rows=other[:4]))
+    odd.append(dict(frame=i, rmse_fp32=float(r32[i].rmse), rmse_fp16x3=float(r3[i].rmse), threshold_crossings=cross, moved_unusable_rows=other[:4]))
     print('camera differs, no usable index moved:', odd[-1])
-res['bf16x3']['cameras_differ_without_moved_usable_index'] = odd
+res['fp16x3']['cameras_differ_without_moved_usable_index'] = odd
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'parity_large_{N}_rowgain{row_gain}.json'), 'w'), indent=1)
+res['split_type'] = sncal_amd._lib.lib().sncal_x3_name().decode()
+tag = os.environ.get('PARITY_TAG', res['split_type'])
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'parity_large_{N}_rowgain{row_gain}_{tag}.json'), 'w'), indent=1)

@@ -8,15 +8,15 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         k = r['Kernel_Name']
         m = re.search(r'conv_(?:group_)?kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
         if 'conv_tt_kernel' in k:
-            mode = 'fp8' if ('ILb1' in k or '<true>' in k or 'ILi1E' in k or 'kernel<1>' in k) else 'bf16x3' if ('ILi2E' in k or 'kernel<2>' in k) else 'bf16'
+            mode = 'fp8' if ('ILb1' in k or '<true>' in k or 'ILi1E' in k or 'kernel<1>' in k) else 'fp16x3' if ('ILi2E' in k or 'kernel<2>' in k) else 'bf16'
             k = 'conv_tt<%s,k3,s1,%s>' % (mode, '12x32x64' if 'c23' in k else '8x32x96')
         elif m:
-            ty = {'DF16b': 'bf16', 'NS_4x3_tE': 'bf16x3'}.get(m.group(1), 'f32')
+            ty = {'DF16b': 'bf16', 'NS_4x3_tE': 'fp16x3'}.get(m.group(1), 'f32')
             k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((ty,) + m.groups()[1:])
         else:
             m2 = re.search(r'conv_(?:group_)?kernel<(.*?), (\d), (\d), (\d), (\d), (\d)>', k)
             if m2:
-                ty = 'bf16' if 'bf16' in m2.group(1) else 'bf16x3' if 'x3_t' in m2.group(1) else 'f32'
+                ty = 'bf16' if 'bf16' in m2.group(1) else 'fp16x3' if 'x3_t' in m2.group(1) else 'f32'
                 k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((ty,) + m2.groups()[1:])
             else:
                 k = ('headx3_fused' if 'headx3_kernel' in k else 'head_fused' if ('head_fused' in k or 'head32_kernel' in k) else

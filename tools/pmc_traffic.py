@@ -3,7 +3,7 @@ and a markdown table.  HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gf
 import json, sys, os
 d = sys.argv[1]; tag = sys.argv[2]; batch = sys.argv[3] if len(sys.argv) > 3 else '64'
 f, w = {}, {}
-for dd in d.split(','):          # one directory per engine (tools/round_profile.sh: bf16x3 and bf16 passes), merged
+for dd in d.split(','):          # one directory per engine (tools/round_profile.sh: fp16x3 and bf16 passes), merged
     f.update(json.load(open(os.path.join(dd, 'FETCH_SIZE', 'summary.json')))); w.update(json.load(open(os.path.join(dd, 'WRITE_SIZE', 'summary.json'))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {'note': f'per-launch HBM bytes from PMC at sub-batch {batch} (profiles/{tag}_pmc_hbm_traffic.md)'}
@@ -19,7 +19,7 @@ for k in f:
 json.dump(out, open(os.path.join(root, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
 with open(os.path.join(root, 'profiles', f'{tag}_pmc_hbm_traffic.md'), 'w') as md:
     md.write(f'# HBM traffic per launch from PMC counters ({tag})\n\n'
-             f'Two separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace -M --output-format csv -- python tools/dev_bench.py {batch} <bf16x3 | bf16> 1`,\n'
+             f'Two separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace -M --output-format csv -- python tools/dev_bench.py {batch} <fp16x3 | bf16> 1`,\n'
              'same with `WRITE_SIZE`; tools/pmc_pass.sh).  FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of a\n'
              'wide coalesced read stream, so reads are doubled (MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated.\n\n'
              '| kernel | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | HBM MB/launch |\n|---|---|---|---|\n')

@@ -11,7 +11,7 @@ python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c
 python bench.py --dtype fp8 --no-cpu-baseline > $O/bench_c3_fp8.json 2> $O/bench_c3_fp8.err
 python bench.py --dtype fp8 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5_fp8.err
 python bench.py --dtype bf16 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
-python bench.py --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16x3.json 2> $O/bench_c5_bf16x3.err
+python bench.py --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp16x3.json 2> $O/bench_c5_fp16x3.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof32 -o trace -- py
 find $O/prof32 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_fp32.csv \;
 find $O/prof32 -name "*.csv" -size +2M -delete
 cd $R
-PMC_B=64 PMC_DTYPE=bf16x3 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc.log 2>&1
+PMC_B=64 PMC_DTYPE=fp16x3 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc.log 2>&1
 PMC_B=64 PMC_DTYPE=bf16 bash tools/pmc_pass.sh $tag/pmc_bf16 "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc_bf16.log 2>&1
 head -c 1500 $O/bench_c3.json; echo; head -c 600 $O/bench_c3_bf16.json; echo; head -c 600 $O/bench_c4.json; echo; head -c 600 $O/bench_c3_fp8.json; echo; head -c 600 $O/bench_c5_fp8.json; echo; head -c 600 $O/bench_c5_bf16.json; echo
 head -8 $O/kernel_stats.csv; tail -30 $O/pmc.log

@@ -92,17 +92,26 @@ def _desc(cfg):
 
 
 class HRNetHeatmap:
-    """Inference-only HRNet on the HIP engine.  ``dtype``: 'fp32' (default: the reference's arithmetic, exact-fp32 MFMA engine),
-    'bf16' (throughput mode) or 'fp8' (bf16 engine with e4m3 wide convolutions, BASELINE config C5)."""
+    """Inference-only HRNet on the HIP engine.  ``dtype``:
+      None / 'fp16x3'  (default) the fp32-class engine: fp32 tensors and accumulation, every product as hi.hi + hi.lo + lo.hi of fp16
+                       splits on the 16-bit matrix pipe -- the engine bench.py measures; on 2048 deep-path frames it returned the exact
+                       engine's keypoint indices on 39642 of 39642 usable rows and its camera on 2045 of 2045 frames
+                       (profiles/r04_parity_large_*); 'bf16x3' names the same engine built on bf16 splits (-DSNCAL_X3_F16=0)
+      'fp32'           the reference's own arithmetic on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 2.8x slower
+      'bf16' / 'fp8'   OPT-IN throughput modes (bf16 tensors; e4m3 wide convolutions, BASELINE config C5): 1-3 % of the usable
+                       keypoints move by one heatmap cell."""
 
     def __init__(self, hrnet_config, num_refinement_stages: int = 0, num_heatmaps: int = None,
-                 dtype: str = 'fp32', device='cuda:0', head=None, upscale=None):
+                 dtype: str = None, device='cuda:0', head=None, upscale=None):
         if num_refinement_stages != 0:
             raise _lib.SncalError('refinement stages are never instantiated by the reference configs; unsupported')
         self.cfg = load_config(hrnet_config, head=head, upscale=upscale)
+        self._L = _lib.lib()
+        if dtype is None:
+            dtype = self._L.sncal_x3_name().decode()
+        self.dtype_name = dtype
         self.dtype = DTYPES[dtype]
         self.device = torch.device(device)
-        self._L = _lib.lib()
         if dtype in ('fp16x3', 'bf16x3') and dtype != self._L.sncal_x3_name().decode():
             raise _lib.SncalError(f"dtype {dtype!r}: this libsncal.so implements the split-arithmetic engine as "
                                   f"{self._L.sncal_x3_name().decode()!r} (rebuild with -DSNCAL_X3_F16={int(dtype == 'fp16x3')} for the other split type)")

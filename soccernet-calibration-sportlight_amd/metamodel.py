@@ -20,7 +20,7 @@ class HRNetMetaModel:
     head = None
     upscale = None
 
-    def __init__(self, params: dict, dtype: str = 'fp32'):
+    def __init__(self, params: dict, dtype: str = None):
         self.params = params
         dev = params.get('device', 'cuda:0')
         self.device = torch.device(dev[0] if isinstance(dev, (list, tuple)) else dev)
@@ -57,13 +57,14 @@ class EHMMetaModel(HRNetMetaModel):
 _MODELS = {'HRNetMetaModel': HRNetMetaModel, 'EHMMetaModel': EHMMetaModel}
 
 
-def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str = 'fp32', **_ignored):
+def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str = None, **_ignored):
     """argus.load_model(path, loss=None, optimizer=None, device=...) for the two inference models.
-    dtype: 'fp32' (default) is the reference's own arithmetic (predict() is fp32, metamodel.py:127-134) on the exact-fp32 MFMA
-    engine -- the only engine that reproduces the reference's keypoint indices.  'bf16' / 'fp8' are OPT-IN throughput modes:
-    measured on the deep-path workload (tests/test_parity_gpu.py, profiles/r03_parity_deep_*.json) they move 1-3 % of the usable
-    keypoints by one heatmap cell (near-ties of the fp32 heatmap) and change the reprojection error by more than 1e-4 on about a
-    third of the frames."""
+    dtype: None (default) = 'fp16x3', the fp32-class engine bench.py measures (fp32 tensors, split-fp16 products, fp32 accumulation):
+    on 2048 deep-path frames it reproduced the exact engine's keypoint indices on every usable row and its camera on every frame
+    (tools/parity_large.py, profiles/r04_parity_large_*), and the reference capture's indices on the W48 golden.  'fp32' is the
+    reference's own arithmetic (predict() is fp32, metamodel.py:127-134) on the exact-fp32 MFMA engine, 2.8x slower.  'bf16' / 'fp8'
+    are OPT-IN throughput modes: they move 1-3 % of the usable keypoints by one heatmap cell (near-ties of the fp32 heatmap) and
+    change the reprojection error by more than 1e-4 on about a third of the frames (tests/test_parity_gpu.py)."""
     try:
         state = torch.load(file_path, map_location='cpu', weights_only=False)
     except ModuleNotFoundError as e:       # checkpoints written under hydra pickle OmegaConf nodes inside params

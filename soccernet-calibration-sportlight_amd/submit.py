@@ -63,7 +63,7 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
         img_names = [n for n in os.listdir(img_dir) if n.endswith('.jpg')]          # make_submit.py:56
     total = len(img_names)
     if total == 0:
-        return {'frames': 0, 'written': 0, 'completeness': 0.0}
+        return {'frames': 0, 'written': 0, 'completeness': 0.0, 'skipped': []}
     H, W = run_frame_size(img_dir, img_names)
     net = model.nn_module
     pt = model.prediction_transform
@@ -140,7 +140,10 @@ def main(argv=None):
     ap.add_argument('--lines-file', default=None, help='lines pickle of export_line_result.py (optional)')
     ap.add_argument('--batch-size', type=int, default=64)
     ap.add_argument('--device', default='cuda:0')
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='fp32: the reference\'s arithmetic (default); bf16: throughput mode, keypoints may move by one cell on near-ties')
+    ap.add_argument('--dtype', default=None, choices=['fp16x3', 'bf16x3', 'fp32', 'bf16', 'fp8'],
+                    help='default: the fp32-class engine of the build (fp16x3: split-fp16 products, fp32 accumulation -- the exact engine\'s '
+                         'keypoint indices on every measured frame); fp32: the reference\'s own arithmetic on the fp32 MFMA, 2.8x slower; '
+                         'bf16 / fp8: throughput modes, keypoints may move by one cell on near-ties')
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise _lib.SncalError('no GPU visible: this package has no CPU path')

@@ -11,18 +11,23 @@ DECODED -- the data dependency of the real path.  --workload c4 adds the line ne
 decode and the on-device line join in front of the same solve (BASELINE config C4).
 
 Data.  No trained checkpoint ships with the reference and random-init weights give flat heatmaps whose argmax cannot
-drive the solve.  The workload therefore keeps the random-init W48 network and installs one designed signal path
-(sncal_amd.synth.peaked_state_dict / stamped_frames): frames carry per-keypoint code stamps at the projections of the
-pitch template through sampled broadcast cameras, the matched stem filters feed the head, and the heatmaps come out
-peaked (p ~ 0.99) on known cells for the visible keypoints on top of the random network's noise -- what a trained
-network hands to HRNetPredictionTransform / CameraCreator.  Every convolution runs at its full size on dense data.
+drive the solve.  The workload therefore keeps the random-init W48 network and installs a designed signal path THROUGH IT
+(sncal_amd.synth.peaked_state_dict(deep=True) = deep_state_dict / stamped_frames): frames carry per-keypoint code stamps at the
+projections of the pitch template through sampled broadcast cameras; the code of keypoint class k travels through channel k of
+every backbone tensor (stem, Bottlenecks, transitions, every BasicBlock of every branch, every fuse layer) and reaches the head
+through the upsampled branch channels, on top of the random network's noise.  The heatmaps come out peaked on known cells for the
+visible keypoints -- what a trained network hands to HRNetPredictionTransform / CameraCreator -- and every arithmetic error of a
+fast engine inside the backbone acts on the decoded keypoints.  Every convolution runs at its full size on dense data.
 
-Engine.  The benchmarked engine is `fp16x3` (default): fp32 tensors and fp32 accumulation, every product formed on the bf16 matrix
-pipe from split operands (x = hi + lo fp16; hi.hi + hi.lo + lo.hi) -- the fastest engine of the build that returns the fp32 engine's
-keypoint indices (the reference's predict() is fp32, metamodel.py:127-134; north_star asks for bit-identical indices): all usable
-keypoints of the benchmarked frames (`parity` on the line), 19 786 of 19 789 on 1024 frames, the three others being ties below 2e-5 in the
-fp32 heatmap (tools/parity_large.py).  The bf16 throughput engine (3x faster, 1-3 % of the usable keypoints move by one cell on the deep-path workload) and the
-exact-fp32 engine are timed on the same frames outside the timed region and ride on the line as `bf16` and `fp32`.
+Engine.  The benchmarked engine is `fp16x3` (default, and load_model's default): fp32 tensors and fp32 accumulation, every product
+formed on the 16-bit matrix pipe from split operands (x = hi + lo, two fp16; hi.hi + hi.lo + lo.hi: the dropped term is ~2^-22 of a
+product) -- the fastest engine of the build that returns the fp32 engine's keypoint indices (the reference's predict() is fp32,
+metamodel.py:127-134; north_star asks for bit-identical indices): all usable keypoints of the benchmarked frames (`parity` on the
+line) and 39 642 of 39 642 on 2048 frames with 2045 of 2045 cameras identical (tools/parity_large.py).  `roofline.peak`
+is the 16-bit dense MFMA peak / 3 (three executed products per reference product); `roofline.frac_of_16bit_dense_peak` prices the
+same reference-formulation work against the undivided hardware peak.  The bf16 throughput engine (2.6x faster, 1-3 % of the usable
+keypoints move by one cell on this workload) and the exact-fp32 engine are timed on the same frames outside the timed region and
+ride on the line as `bf16` and `fp32`.
 
 Parity of the benchmarked path rides on the same line (`parity`, computed OUTSIDE the timed region on the same frames):
 the benchmarked engine against this build's exact-fp32 engine (the one pinned to the reference goldens by
@@ -584,7 +589,7 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (noise frames stamped with per-keypoint codes at the pitch template\'s projections through sampled cameras; '
-                    'random-init HRNet-W48 plus one matched-filter signal path -> peaked heatmaps; see bench.py docstring)',
+                    'random-init HRNet-W48 with the deep signal path of synth.deep_state_dict: the codes travel through every backbone tensor -> peaked heatmaps; see bench.py docstring)',
             'config': {'workload': wl, 'frames_per_gpu': B, 'lanes': L,
                        'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
                        'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}', 'solver': {'refine_cap': cap_note},
@@ -592,7 +597,8 @@ def main():
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * flop_frame / 1e12, 1),
                        'kernel_time_share_last_warmup_step': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(warm, key=lambda q: -q['ms'])[:8]}},
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(ach / peak, 4), 'traffic': traffic, 'launches': dom['launches'],
+                         'frac': round(ach / peak, 4), 'frac_of_16bit_dense_peak': round(ach / (PEAK_TFLOPS['fp8'] if 'fp8' in dom['kernel'] else 2500.0), 4),
+                         'traffic': traffic, 'launches': dom['launches'],
                          'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                          'flops_per_launch': round(dom['flops'] / dom['launches'], 0),
                          'share_of_gpu_time': round(warm_dom['ms'] / total_ms, 4)},

@@ -1,4 +1,5 @@
 #!/bin/bash
-python tools/dev/golden_err.py 2>&1 | grep -v amdgpu.ids
-SNCAL_LIB_PATH=tools/ab/libsncal_bf16x3.so python tools/dev/golden_err.py 2>&1 | grep "bf16x3"
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "fp16x3" 2>&1 | tail -4
+for i in 1 2; do
+echo "--- new"; DEV_TOP=3 timeout 300 python tools/dev_bench.py 64 fp16x3 5 2>&1 | grep -v amdgpu.ids
+echo "--- prev"; SNCAL_LIB_PATH=tools/ab/libsncal_prev.so DEV_TOP=3 timeout 300 python tools/dev_bench.py 64 fp16x3 5 2>&1 | grep -v amdgpu.ids
+done

@@ -24,7 +24,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof32 -o trace -- py
 find $O/prof32 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_fp32.csv \;
 find $O/prof32 -name "*.csv" -size +2M -delete
 cd $R
-PMC_B=64 PMC_DTYPE=fp16x3 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc.log 2>&1
-PMC_B=64 PMC_DTYPE=bf16 bash tools/pmc_pass.sh $tag/pmc_bf16 "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > $O/pmc_bf16.log 2>&1
+# (PMC passes: tools/pmc_pass.sh in a call of their own BEFORE this script -- `python tools/pmc_traffic.py` turns them into
+#  profiles/pmc_traffic.json, which the bench lines above read for roofline.traffic)
+python tools/parity_large.py 4096 0.35 > $O/parity_large_4096.log 2>&1
+python tools/latency.py > $O/latency.log 2>&1
+SNCAL_BBX_TRACE=$O/bbx.bin python tools/dev/bbx_trace_run.py > /dev/null 2>&1; python tools/bbx_trace.py $O/bbx.bin > $O/bbx_trace.txt 2>&1; rm -f $O/bbx.bin
 head -c 1500 $O/bench_c3.json; echo; head -c 600 $O/bench_c3_bf16.json; echo; head -c 600 $O/bench_c4.json; echo; head -c 600 $O/bench_c3_fp8.json; echo; head -c 600 $O/bench_c5_fp8.json; echo; head -c 600 $O/bench_c5_bf16.json; echo
-head -8 $O/kernel_stats.csv; tail -30 $O/pmc.log
+head -8 $O/kernel_stats.csv; tail -12 $O/parity_large_4096.log; cat $O/bbx_trace.txt

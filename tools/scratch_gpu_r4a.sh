@@ -1,5 +1,5 @@
 #!/bin/bash
-for i in 1 2; do
-echo "--- new"; DEV_TOP=3 timeout 300 python tools/dev_bench.py 64 fp16x3 5 2>&1 | grep -v amdgpu.ids
-echo "--- prev"; SNCAL_LIB_PATH=tools/ab/libsncal_prev.so DEV_TOP=3 timeout 300 python tools/dev_bench.py 64 fp16x3 5 2>&1 | grep -v amdgpu.ids
-done
+tag=r04v20
+PMC_B=64 PMC_DTYPE=fp16x3 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > gpurun_out/$tag.pmc.log 2>&1
+PMC_B=64 PMC_DTYPE=bf16 bash tools/pmc_pass.sh $tag/pmc_bf16 "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > gpurun_out/$tag.pmc_bf16.log 2>&1
+tail -12 gpurun_out/$tag.pmc.log

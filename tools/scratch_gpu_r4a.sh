@@ -1,5 +1,4 @@
 #!/bin/bash
-tag=r04v20
-PMC_B=64 PMC_DTYPE=fp16x3 bash tools/pmc_pass.sh $tag/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > gpurun_out/$tag.pmc.log 2>&1
-PMC_B=64 PMC_DTYPE=bf16 bash tools/pmc_pass.sh $tag/pmc_bf16 "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" > gpurun_out/$tag.pmc_bf16.log 2>&1
-tail -12 gpurun_out/$tag.pmc.log
+for v in 1 0 1 0; do
+echo "--- mix $v"; SNCAL_TT_MIX=$v DEV_TOP=1 timeout 300 python tools/dev_bench.py 64 fp16x3 5 2>&1 | grep "conv_tt\|ms/step"
+done

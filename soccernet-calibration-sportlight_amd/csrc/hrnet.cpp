@@ -1019,6 +1019,11 @@ int prepare_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, ConvParams& p
     p.Hout = to.H; p.Wout = to.W; p.cout_frags = L.cout_frags; p.cout = L.cout;
     p.out_cstride = to.C; p.out_coff = op.out_coff;
     p.cin_chunks = L.chunks; p.relu = op.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
+    // one IMAGE of the input / output tensor is a buffer-descriptor range in the kernel (int byte counts, out-of-range sentinel 0x80000000)
+    if ((size_t)ti.H * ti.W * ti.C * 4 >= (1u << 31) || (size_t)to.H * to.W * to.C * 4 >= (1u << 31)) {
+        set_error("conv %s: one image of a tensor reaches 2 GB (%dx%dx%d -> %dx%dx%d): unsupported", L.name.c_str(), ti.H, ti.W, ti.C, to.H, to.W, to.C);
+        return SNCAL_ERR_UNSUPPORTED;
+    }
     // pick NI / tile shape / sub-tiles per weight chunk for this spatial size
     bestv = nullptr;
     best_lds = 0;
@@ -1112,8 +1117,12 @@ bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb) {
     const Tensor& to = net.tensors[op.out];
     if (net.x3) {                                   // bf16x3 engine: fp32 tensors, split twin in, fp32 out
         if (net.dtype != SNCAL_F32 || !L.d_w_x3 || ti.C != L.cin || ti.twin < 0 || to.C % 8 || op.out_coff % 8) return false;
+        // every whole-tensor byte count the kernel forms (input twin, fp32 output, output twin, residual) stays below 2^31: its epilogue
+        // relies on voffset 0x80000000 + soffset being out of range for masked lanes, which only holds for ranges below that
         const size_t in_bytes = (size_t)sb * ti.H * ti.W * ti.C * 4, out_bytes = (size_t)sb * to.H * to.W * to.C * 4;
-        return in_bytes < (1u << 31) && out_bytes < (1ull << 32) && (size_t)((L.cout + TT_COUT - 1) / TT_COUT) * (L.cin / 16) * 9 * 6 * 1024 < (1u << 31);
+        const size_t twin_bytes = (size_t)sb * to.H * to.W * L.cout * 4;
+        return in_bytes < (1u << 31) && out_bytes < (1u << 31) && twin_bytes < (1u << 31) &&
+               (size_t)((L.cout + TT_COUT - 1) / TT_COUT) * (L.cin / 16) * 9 * 6 * 1024 < (1u << 31);
     }
     if (net.dtype != SNCAL_BF16 || op.out_f32) return false;
     if (!L.d_w_tt || ti.C != L.cin) return false;                                   // packed at finalize for the eligible shapes

@@ -363,6 +363,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
         };
         // software pipeline over k-steps: fragments of step s+1 are fetched from LDS while step s multiplies
         frag a[2][MI], b[2][NI];
+        x3h x3_wprev[Elem<T>::X3 ? MI : 1][4], x3_hprev[Elem<T>::X3 ? NI : 1][4];      // x3_t: hi halves of the even k-step of a pair
         {
             const int off = frag_off(0);
 #pragma unroll
@@ -389,24 +390,43 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 // B fragment -- and WRONG on gfx950 as hipcc 7.2 schedules it: back to back behind the K = 32 instruction whose vDst it
                 // reads as SrcC, with no wait states; accumulator registers 0 and 1 of such tiles came out wrong.  Found by the per-kernel
                 // test, isolated by tools/dev/mfma_pair_probe.hip.)
-                x3h8 bx[NI], bm[NI];
+                // Round 4: the main terms of TWO consecutive k-steps share one instruction -- A = [w_hi(s) | w_hi(s + 1)] against
+                // B = [x_hi(s) | x_hi(s + 1)], both halves taken from registers the steps hold anyway -- so a pair of steps costs 3 MFMAs
+                // instead of 4 (an odd last step keeps its own main term against [x_hi | 0]).
+                x3h8 bx[NI];
+                x3h hcur[NI][4];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    x3h h[4], l[4];
+                    x3h l[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X3_SPLIT(b[cur][j][e], h[e], l[e]);
-                    const x3h z = (x3h)0.0f;
-                    bx[j] = x3h8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
-                    bm[j] = x3h8{h[0], h[1], h[2], h[3], z, z, z, z};
+                    for (int e = 0; e < 4; ++e) X3_SPLIT(b[cur][j][e], hcur[j][e], l[e]);
+                    bx[j] = x3h8{l[0], l[1], l[2], l[3], hcur[j][0], hcur[j][1], hcur[j][2], hcur[j][3]};
                 }
+                const bool second = (s & 1) != 0, alone = !second && s + 1 == NKS;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const x3h8 aw = __builtin_bit_cast(x3h8, a[cur][mi]);
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[mi][j] = X3_MFMA_16x16x32(aw, bx[j], acc[mi][j]);
-                        acc[mi][j] = X3_MFMA_16x16x32(aw, bm[j], acc[mi][j]);
+                    for (int j = 0; j < NI; ++j) acc[mi][j] = X3_MFMA_16x16x32(aw, bx[j], acc[mi][j]);
+                    if (second || alone) {
+                        const x3h z = (x3h)0.0f;
+                        const x3h8 am = second ? x3h8{x3_wprev[mi][0], x3_wprev[mi][1], x3_wprev[mi][2], x3_wprev[mi][3], aw[0], aw[1], aw[2], aw[3]} : aw;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const x3h8 bm = second ? x3h8{x3_hprev[j][0], x3_hprev[j][1], x3_hprev[j][2], x3_hprev[j][3], hcur[j][0], hcur[j][1], hcur[j][2], hcur[j][3]}
+                                                   : x3h8{hcur[j][0], hcur[j][1], hcur[j][2], hcur[j][3], z, z, z, z};
+                            acc[mi][j] = X3_MFMA_16x16x32(am, bm, acc[mi][j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x3_wprev[mi][e] = aw[e];
                     }
+                }
+                if (!second && !alone) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x3_hprev[j][e] = hcur[j][e];
                 }
             } else {
 #pragma unroll

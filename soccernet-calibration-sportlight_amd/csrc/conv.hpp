@@ -399,7 +399,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 for (int j = 0; j < NI; ++j) {
                     x3h l[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X3_SPLIT(b[cur][j][e], hcur[j][e], l[e]);
+                    for (int e = 0; e < 4; ++e) X3_SPLIT1(b[cur][j][e], hcur[j][e], l[e]);
                     bx[j] = x3h8{l[0], l[1], l[2], l[3], hcur[j][0], hcur[j][1], hcur[j][2], hcur[j][3]};
                 }
                 const bool second = (s & 1) != 0, alone = !second && s + 1 == NKS;
@@ -612,7 +612,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                             if (has_twin) {        // wave-uniform: [16 hi | 16 lo] bf16 per pixel and 16-channel group, this lane's 4 channels are 8 + 8 bytes
                                 x3h4 th, tl;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], th[e], tl[e]);
+                                for (int e = 0; e < 4; ++e) X3_SPLIT1(v[e], th[e], tl[e]);
                                 const unsigned c16 = (unsigned)(grp * 4) & 15u;          // (nb * CO is a multiple of 16)
                                 const unsigned toff = o == 0x80000000u ? o : o - c16 * 2;  // byte offset of the group's hi half + this lane's 8 bytes
                                 u32x2 t0 = __builtin_bit_cast(u32x2, th), t1 = __builtin_bit_cast(u32x2, tl);
@@ -666,7 +666,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                     const float v[4] = {v0, v1, v2, v3};
                     x3h4 th, tl;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], th[e], tl[e]);
+                    for (int e = 0; e < 4; ++e) X3_SPLIT1(v[e], th[e], tl[e]);
                     char* const tw = reinterpret_cast<char*>(p.out_twin) + (pix * p.cout + (co & ~15)) * 4 + (co & 15) * 2;
                     *reinterpret_cast<x3h4*>(tw) = th;
                     *reinterpret_cast<x3h4*>(tw + 32) = tl;

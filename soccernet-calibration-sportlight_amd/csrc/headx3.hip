@@ -16,6 +16,8 @@
 // and column maxima of the tile) are head32.hip's; a workgroup holds 51 KB of LDS (three per CU).
 #include "common.hpp"
 #include "head.hpp"
+#include <vector>
+#include <cstdio>
 #include "softmax_px.hpp"
 #include "x3.hpp"
 #include <cstdio>
@@ -32,12 +34,26 @@ typedef __attribute__((address_space(3))) void lds_void;
 namespace {
 constexpr int KS = 13, RB = 2;
 constexpr int X_SRC = 16 * 1024;                    // 4 waves x 2 sources x 2 KB (16 box pixels x 32 channels fp32)
-constexpr int OFF_W0H = X_SRC, OFF_W0L = OFF_W0H + KS * 1024, OFF_W1H = OFF_W0L + KS * 1024, OFF_W1L = OFF_W1H + RB * 2 * 1024;
-constexpr int OFF_B0 = OFF_W1L + RB * 2 * 1024, X_LDS = OFF_B0 + 1024;      // 52224 B
+// Stage-1 weights and shift are DOUBLE-buffered (round 4): the kernel holds 232 VGPRs (104 of them the resident stage-1 B fragments), so
+// two workgroups share a CU and 2 x 78 KB of LDS fit; slice q + 1's 27 KB land while slice q multiplies.
+constexpr int W0_BUF = 2 * KS * 1024 + 1024;        // [W0 hi 13 KB][W0 lo 13 KB][shift 1 KB]
+constexpr int OFF_W0 = X_SRC, OFF_W1H = OFF_W0 + 2 * W0_BUF, OFF_W1L = OFF_W1H + RB * 2 * 1024, X_LDS = OFF_W1L + RB * 2 * 1024;      // 79872 B
+static_assert(2 * X_LDS <= 160 * 1024, "two workgroups per CU");
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// One LDS-DMA piece as inline assembly (64 lanes x 16 bytes -> 1 KB at LDS byte address `lds_addr`): hipcc's wait-count pass would put
+// vmcnt(0) in front of every fragment read behind a DMA builtin, i.e. wait for the NEXT slice's pieces; every wait here is explicit.
+__device__ __forceinline__ void dma_piece(i32x4_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4_t raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return i32x4_t{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) X3_SPLIT(v[e], h[e], l[e]);
+    for (int e = 0; e < 8; ++e) X3_SPLIT1(v[e], h[e], l[e]);
 }
 __device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
     acc = X3_MFMA_32x32x16(al, bh, acc);
@@ -48,6 +64,7 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, cons
 
 template <int DEC>
 __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
+    const unsigned long long t_begin = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,39 +120,46 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
         split8(wv, wih[s], wil[s]);
     }
 
-    const __amdgpu_buffer_rsrc_t rs_w0h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w0_32), 0, p.NQ * KS * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w0l = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w0_32_lo), 0, p.NQ * KS * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w1h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1_32), 0, p.NQ * RB * 2 * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w1l = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1_32_lo), 0, p.NQ * RB * 2 * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias0), 0, p.HP * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_src[2];
+    const i32x4_t rs_w0h = raw_rsrc(p.w0_32, (unsigned)(p.NQ * KS * 1024)), rs_w0l = raw_rsrc(p.w0_32_lo, (unsigned)(p.NQ * KS * 1024));
+    const i32x4_t rs_w1h = raw_rsrc(p.w1_32, (unsigned)(p.NQ * RB * 2 * 1024)), rs_w1l = raw_rsrc(p.w1_32_lo, (unsigned)(p.NQ * RB * 2 * 1024));
+    const i32x4_t rs_b0 = raw_rsrc(p.bias0, (unsigned)(p.HP * 4));
+    i32x4_t rs_src[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const size_t img = (size_t)p.Hs[s] * p.Ws[s] * p.HP * 4;      // one fp32 image of source s
-        rs_src[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.src[s])) + (size_t)n * img, 0, (int)img, 0x00020000);
+        rs_src[s] = raw_rsrc(reinterpret_cast<const char*>(p.src[s]) + (size_t)n * img, (unsigned)img);
     }
-    auto issue_slice = [&](int q) {
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_void*)smem;
+    // the three request groups of a slice.  Boxes: this wave's own region (private: requested as soon as the wave has read the old ones);
+    // stage-1 weights + shift: buffer q & 1, requested one slice ahead; stage-2 weights: single-buffered, requested at the top of their slice
+    auto issue_boxes = [&](int q) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src[s], (lds_void*)(smem + ((wave * 2 + s) * 2 + j) * 1024), 16, dma_voff[s][j], (unsigned)(q * 128), 0, 0);
+            for (int j = 0; j < 2; ++j) dma_piece(rs_src[s], lds0 + ((wave * 2 + s) * 2 + j) * 1024, dma_voff[s][j], (unsigned)(q * 128));
+    };
+    auto issue_w0 = [&](int q) {
+        const unsigned base = lds0 + OFF_W0 + (q & 1) * W0_BUF;
 #pragma unroll
         for (int i = 0; i < (KS + 3) / 4; ++i)
             if (wave + 4 * i < KS) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0h, (lds_void*)(smem + OFF_W0H + (wave + 4 * i) * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0l, (lds_void*)(smem + OFF_W0L + (wave + 4 * i) * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024), 0, 0);
+                dma_piece(rs_w0h, base + (wave + 4 * i) * 1024, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024));
+                dma_piece(rs_w0l, base + KS * 1024 + (wave + 4 * i) * 1024, (unsigned)(lane * 16), (unsigned)((q * KS + wave + 4 * i) * 1024));
             }
-        // RB * 2 = 4 pieces each: one per wave
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1h, (lds_void*)(smem + OFF_W1H + wave * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1l, (lds_void*)(smem + OFF_W1L + wave * 1024), 16, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024), 0, 0);
-        if (wave == 3)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b0, (lds_void*)(smem + OFF_B0), 16, lane < 8 ? (unsigned)(lane * 16) : 0x80000000u, (unsigned)(q * 128), 0, 0);
+        if (wave == 3) dma_piece(rs_b0, base + 2 * KS * 1024, lane < 8 ? (unsigned)(lane * 16) : 0x80000000u, (unsigned)(q * 128));
     };
-    issue_slice(0);
+    auto issue_w1 = [&](int q) {       // RB * 2 = 4 pieces each: one per wave
+        dma_piece(rs_w1h, lds0 + OFF_W1H + wave * 1024, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024));
+        dma_piece(rs_w1l, lds0 + OFF_W1L + wave * 1024, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024));
+    };
+    issue_boxes(0);
+    issue_w0(0);
 
     // ---- stage-1 B fragments, split: K = [direct channels | upsampled narrow branches]; lane (pixel l31, k-block hi) holds channels
     // 16 ks + 8 hi .. + 7 of its pixel.  Segment boundaries are multiples of 8 channels.
+    // (A branch-free form of this loop -- every k-step a four-tap blend, the loads of 4 + 4 + 2 + 2 + 1 k-steps in flight together --
+    // was measured in round 4: the prologue stayed at ~30k clocks of a workgroup's ~166k.  It is bound by the number of cache lines the
+    // taps touch (64 B per pixel, tap and k-step), not by 13 serial trips to HBM.)
     bf16x8 bDh[KS], bDl[KS];
     const float* direct = reinterpret_cast<const float*>(p.direct);
 #pragma unroll
@@ -184,28 +208,42 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
         for (int e = 0; e < 16; ++e) acc2[rb][e] = 0.f;
     const int tch = h32_row_channel(l31);         // hidden channel (within a slice) of this lane's row of a transposed box fragment
 
+    // tuning aid (SNCAL_HEAD_TRACE=<file>, tools/head_trace.py): clocks of wave 0 in [0] barriers + wait, [1] requests, [2] stage 1,
+    // [3] gather, [4] ReLU + stage 2, [5] prologue
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool tracing = p.trace != nullptr;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
+    if (tracing) { tprev = t_begin; lap(5); }
+    // Request order per wave: boxes(0), W0(0) | then per slice q: W1(q), W0(q + 1), boxes(q + 1).  Requests complete in order, so
+    // "at most n newest in flight" (vmcnt(n)) names exactly which older groups have landed; a wave issues 6-9 pieces per W0 group
+    // (the waits use the smallest count, i.e. wait for up to 3 pieces more than needed), 2 per W1 group, 4 per box group.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
     for (int q = 0; q < p.NQ; ++q) {
-        if (q > 0) {
-            asm volatile("s_barrier" ::: "memory");               // everyone is done with slice q - 1
-            issue_slice(q);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my DMA pieces of slice q landed
-        asm volatile("s_barrier" ::: "memory");                   // everyone's did
+        // here: everyone is done with slice q - 1 and everyone's pieces of W0(q) have landed (the barrier at the end of slice q - 1)
+        lap(0);
+        issue_w1(q);                                  // lands under stage 1 + gather
+        if (q + 1 < p.NQ) issue_w0(q + 1);            // lands under the whole slice
+        lap(1);
+        const char* const w0b = smem + OFF_W0 + (q & 1) * W0_BUF;
         // ---- stage 1: 32 hidden channels x 32 pixels, started at the folded-BN shift
         f32x16 acc1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 b0 = *reinterpret_cast<const float4*>(smem + OFF_B0 + (16 * h + 8 * hi) * 4);
-            const float4 b1 = *reinterpret_cast<const float4*>(smem + OFF_B0 + (16 * h + 8 * hi + 4) * 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(w0b + 2 * KS * 1024 + (16 * h + 8 * hi) * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(w0b + 2 * KS * 1024 + (16 * h + 8 * hi + 4) * 4);
             acc1[8 * h + 0] = b0.x; acc1[8 * h + 1] = b0.y; acc1[8 * h + 2] = b0.z; acc1[8 * h + 3] = b0.w;
             acc1[8 * h + 4] = b1.x; acc1[8 * h + 5] = b1.y; acc1[8 * h + 6] = b1.z; acc1[8 * h + 7] = b1.w;
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + OFF_W0H + (ks * 64 + lane) * 16);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(smem + OFF_W0L + (ks * 64 + lane) * 16);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(w0b + (ks * 64 + lane) * 16);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(w0b + KS * 1024 + (ks * 64 + lane) * 16);
             acc1 = mfma3(ah, al, bDh[ks], bDl[ks], acc1);
         }
+        lap(2);
+        // my boxes of slice q (requested after the gather of slice q - 1; newer: W1(q), W0(q + 1)) -- the first slice's landed in the prologue
+        if (q > 0) { if (q + 1 < p.NQ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         // ---- gather: A fragment = the box pixels of this slice, transposed on the fly and split: lane (row l31 -> channel tch, k-block
         // hi) reads box pixels 8 hi .. 8 hi + 7 of its channel (eight 4-byte reads, 128-byte stride)
 #pragma unroll
@@ -218,14 +256,24 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
             split8(tv, th, tl);
             acc1 = mfma3(th, tl, wih[s], wil[s], acc1);
         }
+        if (q + 1 < p.NQ) {             // my boxes are read (tv went through the split): the next slice's travel under stage 2 and stage 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_boxes(q + 1);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // my pieces of W1(q) (newer: W0(q + 1) and the boxes)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");                   // everyone's pieces of W1(q)
+        lap(3);
         // ---- ReLU -> split stage-2 B fragments (a register repack), stage 2: logits += W1[:, q-slice] . h
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float hv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = fmaxf(acc1[8 * h + e], 0.f);
+            for (int e = 0; e < 8; ++e) hv[e] = x3_relu_clamp(acc1[8 * h + e]);
             bf16x8 bh, bl;
-            split8(hv, bh, bl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X3_SPLIT_RAW(hv[e], bh[e], bl[e]);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + OFF_W1H + ((rb * 2 + h) * 64 + lane) * 16);
@@ -233,7 +281,14 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
                 acc2[rb] = mfma3(ah, al, bh, bl, acc2[rb]);
             }
         }
+        lap(4);
+        if (q + 1 < p.NQ) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // my pieces of W0(q + 1) (newer: the boxes)
+            asm volatile("s_barrier" ::: "memory");               // everyone's; and everyone is done with slice q
+        }
     }
+    if (tracing && threadIdx.x == 0 && blockIdx.x % 97 == 0)
+        for (int k = 0; k < 6; ++k) p.trace[(size_t)(blockIdx.x / 97) * 8 + k] = tsum[k];
     if constexpr (DEC) {
         // decode-fused epilogue (head32.hip's): per-pixel log-softmax (softmax_px.hpp: the same arithmetic and summation order as the
         // softmax kernels), then the tile's maxima per class over its 32 columns for every row and over its 4 rows for every column
@@ -307,8 +362,8 @@ bool launch_headx3(const HeadParams& p, hipStream_t s) {
     if (!headx3_applies(p)) return false;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&headx3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
         attr_done = true;
     }
     HeadParams q = p;
@@ -316,10 +371,20 @@ bool launch_headx3(const HeadParams& p, hipStream_t s) {
     q.tiles_y = (p.H + 3) / 4;
     q.tiles_x_magic = q.tiles_x <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_x + 1u;
     q.tiles_y_magic = q.tiles_y <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_y + 1u;
-    q.trace = nullptr;
     const unsigned blocks = (unsigned)(q.tiles_x * q.tiles_y * p.N);
+    static const char* trace_file = getenv("SNCAL_HEAD_TRACE");
+    const size_t n_tr = (size_t)(blocks / 97 + 1) * 8;
+    q.trace = nullptr;
+    if (trace_file && hipMalloc(&q.trace, n_tr * 8) == hipSuccess) (void)hipMemsetAsync(q.trace, 0, n_tr * 8, s);
     if (p.dec_row && p.dec_col) SNCAL_LAUNCH((headx3_kernel<1>), dim3(blocks), dim3(256), (size_t)X_LDS, s, q);
     else SNCAL_LAUNCH((headx3_kernel<0>), dim3(blocks), dim3(256), (size_t)X_LDS, s, q);
+    if (q.trace) {
+        std::vector<unsigned long long> h(n_tr);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), q.trace, n_tr * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, n_tr, f); fclose(f); }
+    }
     return true;
 }
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
             if (p.out_twin) {          // bf16x3: hi = bf16(y), lo = bf16(y - hi) for the two-team convolution that reads this sum
                 x3h4 th, tl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) X3_SPLIT((float)o[e], th[e], tl[e]);
+                for (int e = 0; e < 4; ++e) X3_SPLIT1((float)o[e], th[e], tl[e]);
                 char* const tw = reinterpret_cast<char*>(p.out_twin) + (pix * p.C + (c0 & ~15)) * 4 + (c0 & 15) * 2;
                 *reinterpret_cast<x3h4*>(tw) = th;
                 *reinterpret_cast<x3h4*>(tw + 32) = tl;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict
         const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         x3h8 h, l;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) X3_SPLIT(f[e], h[e], l[e]);
+        for (int e = 0; e < 8; ++e) X3_SPLIT1(f[e], h[e], l[e]);
         const size_t g16 = i >> 1, half = i & 1;            // 16-channel group, which 8 of its channels
         y[g16 * 4 + half] = h;
         y[g16 * 4 + 2 + half] = l;

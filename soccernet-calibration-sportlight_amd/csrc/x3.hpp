@@ -34,6 +34,9 @@ typedef __attribute__((ext_vector_type(4))) x3h x3h4;
 // split: hi = rne16(v), lo = rne16(v - hi).  fp16: |v| is clamped to the format's range FIRST -- a stale or padded operand far outside it
 // (it meets a zero weight, e.g. a gather lane outside its box) must stay finite in BOTH parts: with only hi clamped, lo = v - 65504
 // converted to +inf and inf x 0 poisoned the sum (found by the batch-independence test: the poison depends on what the workspace held).
+// Two spellings of the clamp: fminf(fmaxf()) compiles to a canonicalising v_max plus a v_med3, the intrinsic to the v_med3 alone.  Which
+// one is faster is a matter of the surrounding schedule (measured round 4: the intrinsic gains 4 % in the head and 1.6 % in the generic
+// stride-2 kernel and LOSES 1 % in the fused block and 0.3 % in the two-team kernel), so the call site chooses: X3_SPLIT / X3_SPLIT1.
 __device__ __forceinline__ float x3_clamp(float v) {
 #if SNCAL_X3_F16
     return __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
@@ -41,7 +44,26 @@ __device__ __forceinline__ float x3_clamp(float v) {
     return v;
 #endif
 }
-// (a macro: vector elements do not bind to references)
+__device__ __forceinline__ float x3_clamp1(float v) {
+#if SNCAL_X3_F16
+    return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+#else
+    return v;
+#endif
+}
+// ReLU as ONE instruction (fmaxf(v, 0) is a canonicalising v_max plus the v_max itself when v comes out of an MFMA), and ReLU + clamp
+// as one: the operand of X3_SPLIT_RAW
+__device__ __forceinline__ float x3_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+__device__ __forceinline__ float x3_relu_clamp(float v) {
+#if SNCAL_X3_F16
+    return __builtin_amdgcn_fmed3f(v, 0.f, 65504.f);
+#else
+    return x3_relu(v);
+#endif
+}
+// (macros: vector elements do not bind to references)
+#define X3_SPLIT1(v, hi, lo) do { const float x3v_ = ::sncal::x3_clamp1(v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
+#define X3_SPLIT_RAW(v, hi, lo) do { const float x3v_ = (v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
 #define X3_SPLIT(v, hi, lo) do { const float x3v_ = ::sncal::x3_clamp(v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
 
 // host side (weight packing): the same two codes

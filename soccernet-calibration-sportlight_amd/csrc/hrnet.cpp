@@ -19,6 +19,7 @@
 #include "head.hpp"
 #include "bblock.hpp"
 #include "bblockx3.hpp"
+#include "bneckx3.hpp"
 #include "x3.hpp"
 #include "conv_tt.hpp"
 
@@ -57,6 +58,7 @@ struct ConvLayer {
     int x3_blk = TT_COUT;       // ... packed in output-channel blocks of 96 (tile 96 x 8 x 32) or, for widths that are no multiple of 96, 64 (64 x 12 x 32)
     bool x3_on = false;
     void* d_w_bbx = nullptr;    // bf16x3 engine, 48 -> 48 3x3 layers: pair-step packing of the fused BasicBlock (bblockx3.hip)
+    void* d_w_bnp = nullptr;    // split engines, layer1's 1x1 layers (64 -> 256, 256 -> 64): A fragments of the fused Bottleneck seam (bneckx3.hip)
     // internal layers of the fused head: t_i = W0[:, col_off : col_off + cin] . branch_i  (derived at finalize)
     bool derived = false;
     int col_off = 0;
@@ -137,6 +139,8 @@ struct sncal_hrnet {
     std::vector<char> need_bf16;              // per tensor: some active consumer reads the bf16 tensor
     std::vector<int> producer;                // per tensor: active op that writes it
     bool fuse_bblock = getenv("SNCAL_FUSE_BBLOCK") ? atoi(getenv("SNCAL_FUSE_BBLOCK")) != 0 : true;   // 48-channel BasicBlocks as one kernel (bblock.hip), bf16 path
+    // split engines, layer1 (bneckx3.hip): bit 0 = conv3 of a Bottleneck + conv1 of the next as one pass, bit 1 = block 0's downsample branch inside its conv3
+    int fuse_bneck = getenv("SNCAL_FUSE_BNECK") ? atoi(getenv("SNCAL_FUSE_BNECK")) : 3;
     bool fuse_bbx3 = getenv("SNCAL_FUSE_BBX3") ? atoi(getenv("SNCAL_FUSE_BBX3")) != 0 : true;         // ... and in split arithmetic (bblockx3.hip), bf16x3 engine
     void *d_hw0 = nullptr, *d_hw1 = nullptr;
     void *d_hw0_32 = nullptr, *d_hw1_32 = nullptr;      // head32.hip packing (null when K1 is not a multiple of 16)
@@ -643,6 +647,18 @@ int pack_layer_bbx3(sncal_hrnet& net, ConvLayer& L) {
     bbx3_pack_weights(L.w.data(), L.scale.data(), [](float v, uint16_t* hi, uint16_t* lo) { x3_split_host(v, hi, lo); }, host);
     SNCAL_CHECK_HIP(hipMalloc(&L.d_w_bbx, host.size() * 2));
     SNCAL_CHECK_HIP(hipMemcpy(L.d_w_bbx, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    return SNCAL_OK;
+}
+
+// split engines: a 1x1 layer of layer1 in the fused Bottleneck seam's fragment order (bneckx3.hpp)
+int pack_layer_bnp(sncal_hrnet& net, ConvLayer& L) {
+    if (L.d_w_bnp) { (void)hipFree(L.d_w_bnp); L.d_w_bnp = nullptr; }
+    const bool shape = L.k == 1 && L.stride == 1 && ((L.cin == BNP_MID && L.cout == BNP_WIDE) || (L.cin == BNP_WIDE && L.cout == BNP_MID));
+    if (!net.x3 || net.dtype != SNCAL_F32 || !shape || L.derived) return SNCAL_OK;
+    std::vector<uint16_t> host;
+    bnp_pack_weights(L.w.data(), L.scale.data(), L.cout, L.cin, [](float v, uint16_t* hi, uint16_t* lo) { x3_split_host(v, hi, lo); }, host);
+    SNCAL_CHECK_HIP(hipMalloc(&L.d_w_bnp, host.size() * 2));
+    SNCAL_CHECK_HIP(hipMemcpy(L.d_w_bnp, host.data(), host.size() * 2, hipMemcpyHostToDevice));
     return SNCAL_OK;
 }
 
@@ -1489,7 +1505,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
-    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_oscale) (void)hipFree(L.d_oscale); }
+    for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_bnp) (void)hipFree(L.d_w_bnp); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
@@ -1561,6 +1577,8 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         rc = pack_layer_x3(*net, L);
         if (rc) return rc;
         rc = pack_layer_bbx3(*net, L);
+        if (rc) return rc;
+        rc = pack_layer_bnp(*net, L);
         if (rc) return rc;
         std::vector<float>().swap(L.w);
     }
@@ -1839,7 +1857,84 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             net->layers[nx.conv].x3_on && net->layers[nx.conv].d_w_bbx && tt_eligible(*net, nx, sb) && net->tensors[op.in].C == 48 &&
                             net->tensors[op.in].twin >= 0 && net->tensors[net->tensors[op.in].twin].first >= 0) opx = &nx;
                     }
-                    if (opx) {
+                    // split engines, layer1: conv3 (+ residual, ReLU) of a Bottleneck and conv1 (+ ReLU) of the next one in one pass over the
+                    // pixels (bneckx3.hip): the 256-channel tensor between them is written once (the next residual) and not read back
+                    const Op* opn = nullptr;
+                    const Op* opd = nullptr;        // ... and block 0's tail: this op is the downsample branch, the next one the conv3 that adds it
+                    if ((net->fuse_bneck & 2) && net->x3 && !op.relu && op.res < 0 && !op.out_f32 && op.out_coff == 0 && oi + 1 < net->ops.size() &&
+                        net->layers[op.conv].d_w_bnp && net->layers[op.conv].cout == BNP_WIDE && !net->layers[op.conv].x3_on && op.launch_group < 0) {
+                        const Op& nx = net->ops[oi + 1];
+                        if (nx.type == OP_CONV && op_active(*net, nx) && nx.res == op.out && nx.relu && !nx.out_f32 && nx.out_coff == 0 && nx.launch_group < 0 &&
+                            net->layers[nx.conv].d_w_bnp && net->layers[nx.conv].cout == BNP_WIDE && !net->layers[nx.conv].x3_on &&
+                            net->tensors[op.in].C == BNP_MID && net->tensors[nx.in].C == BNP_MID && net->tensors[nx.out].C == BNP_WIDE &&
+                            net->tensors[op.in].H == net->tensors[nx.in].H && net->tensors[op.in].W == net->tensors[nx.in].W &&
+                            net->tensors[op.out].last == (int)oi + 1) {           // nobody else reads the downsample branch
+                            bool skip_a = false;
+                            if (!producer_twin(*net, nx.out, sb, ws, &skip_a)) opd = &nx;
+                        }
+                    }
+                    if ((net->fuse_bneck & 1) && net->x3 && op.relu && op.res >= 0 && !op.out_f32 && op.out_coff == 0 && oi + 1 < net->ops.size() &&
+                        net->layers[op.conv].d_w_bnp && net->layers[op.conv].cout == BNP_WIDE && !net->layers[op.conv].x3_on) {
+                        const Op& nx = net->ops[oi + 1];
+                        const Tensor& t_in = net->tensors[op.in];
+                        const Tensor& t_res = net->tensors[op.res];
+                        const Tensor& t_y = net->tensors[op.out];
+                        if (nx.type == OP_CONV && op_active(*net, nx) && nx.in == op.out && nx.res < 0 && nx.relu && !nx.out_f32 && nx.out_coff == 0 &&
+                            nx.launch_group < 0 && net->layers[nx.conv].d_w_bnp && net->layers[nx.conv].cout == BNP_MID && !net->layers[nx.conv].x3_on &&
+                            t_in.C == BNP_MID && t_res.C == BNP_WIDE && t_y.C == BNP_WIDE && net->tensors[nx.out].C == BNP_MID &&
+                            t_res.H == t_y.H && t_res.W == t_y.W) {
+                            bool skip_a = false, skip_b = false;         // neither output may owe somebody a split twin (they feed generic kernels)
+                            if (!producer_twin(*net, op.out, sb, ws, &skip_a) && !producer_twin(*net, nx.out, sb, ws, &skip_b)) opn = &nx;
+                        }
+                    }
+                    if (opd) {
+                        const Tensor& t_y = net->tensors[opd->out];
+                        BneckPairParams bp;
+                        memset(&bp, 0, sizeof(bp));
+                        bp.h2 = reinterpret_cast<const float*>(ws + net->tensors[opd->in].offset);
+                        bp.x0 = reinterpret_cast<const float*>(ws + net->tensors[op.in].offset);
+                        bp.y = reinterpret_cast<float*>(ws + t_y.offset);
+                        bp.w3 = net->layers[opd->conv].d_w_bnp; bp.b3 = net->layers[opd->conv].d_bias;
+                        bp.wds = net->layers[op.conv].d_w_bnp; bp.bds = net->layers[op.conv].d_bias;
+                        bp.P = (long long)sb * t_y.H * t_y.W;
+                        if (!net->n_cus) {
+                            int dev = 0, cus = 0;
+                            SNCAL_CHECK_HIP(hipGetDevice(&dev));
+                            SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                            net->n_cus = cus > 0 ? cus : 256;
+                        }
+                        rc = launch_bneck_pair_x3(bp, net->n_cus, stream);
+                        if (net->profiling) {
+                            net->last_kernel = "bneck_tail_ds_x3";
+                            net->last_flops = 2.0 * 2.0 * (double)bp.P * BNP_MID * BNP_WIDE;
+                            net->last_bytes = (double)bp.P * 4.0 * (BNP_MID + BNP_MID + BNP_WIDE) + 2.0 * BNP_W_BYTES;
+                        }
+                        skip_next = true;
+                    } else if (opn) {
+                        const Tensor& t_y = net->tensors[op.out];
+                        BneckPairParams bp;
+                        memset(&bp, 0, sizeof(bp));
+                        bp.h2 = reinterpret_cast<const float*>(ws + net->tensors[op.in].offset);
+                        bp.res = reinterpret_cast<const float*>(ws + net->tensors[op.res].offset);
+                        bp.y = reinterpret_cast<float*>(ws + t_y.offset);
+                        bp.h1 = reinterpret_cast<float*>(ws + net->tensors[opn->out].offset);
+                        bp.w3 = net->layers[op.conv].d_w_bnp; bp.b3 = net->layers[op.conv].d_bias;
+                        bp.w1 = net->layers[opn->conv].d_w_bnp; bp.b1 = net->layers[opn->conv].d_bias;
+                        bp.P = (long long)sb * t_y.H * t_y.W;
+                        if (!net->n_cus) {
+                            int dev = 0, cus = 0;
+                            SNCAL_CHECK_HIP(hipGetDevice(&dev));
+                            SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                            net->n_cus = cus > 0 ? cus : 256;
+                        }
+                        rc = launch_bneck_pair_x3(bp, net->n_cus, stream);
+                        if (net->profiling) {
+                            net->last_kernel = "bneck_seam_x3";
+                            net->last_flops = 2.0 * 2.0 * (double)bp.P * BNP_MID * BNP_WIDE;
+                            net->last_bytes = (double)bp.P * 4.0 * (BNP_MID + BNP_WIDE + BNP_WIDE + BNP_MID) + 2.0 * BNP_W_BYTES;
+                        }
+                        skip_next = true;
+                    } else if (opx) {
                         const Tensor& ti = net->tensors[op.in];
                         const Tensor& to = net->tensors[opx->out];
                         const sncal::LaunchEvents armed = sncal::launch_events();

@@ -269,6 +269,21 @@ def verify_plan(sncal, cuda, cfg, sd, x, dtype, fp8_layers=None, tag=''):
                     checked = True
                 assert checked, name
                 continue
+            if label == 'bneck_tail_ds_x3' and op['kernel'] == 'bneck_tail_ds_x3':
+                # fp16x3, layer1 block 0 (bneckx3.hip): this op is the downsample branch, the next one the conv3 that adds it; one launch
+                # computes ReLU(W3 . h2 + shift3 + Wds . x0 + shift_ds), the 256-channel branch tensor is never written
+                nxt = by_idx[op['idx'] + 1]
+                assert nxt['type'] == 'conv' and nxt['res'] == op['out'] and nxt['relu'] and not op['relu'], 'fused tail shape'
+                fused_second.add(nxt['idx'])
+                w3, shift3 = W.get(nxt)
+                x0 = nchw(T(op, op['in']))[:, :op['cin']]
+                h2 = nchw(taps[(nxt['idx'], nxt['in'])])[:, :nxt['cin']]
+                y = torch.relu(conv_ref(h2, w3, 1) + shift3[None, :, None, None] + conv_ref(x0, w, 1) + shift[None, :, None, None])
+                slack = X3_SLACK * (conv_ref(h2.abs(), w3.abs(), 1) + conv_ref(x0.abs(), w.abs(), 1))
+                to = net.plan_tensor(nxt['out'])
+                got = nchw(taps[(nxt['idx'], nxt['out'])])
+                check(f"{nxt['name']} + downsample {to['H']}x{to['W']} 64+64->256", got, y, rel_out, abs_out + slack, stats, 'bneck_tail_ds_x3')
+                continue
             if op['fp8']:
                 tw = net.plan_tensor(ti['twin'])
                 xin = e4m3_decode(T(op, ti['twin'])).permute(0, 3, 1, 2).contiguous()            # codes
@@ -540,6 +555,9 @@ def test_every_launch_of_the_fp16x3_engine_w48_540p(sncal, cuda):
     n = lambda key: stats.get(key, {'ops': 0})['ops']
     assert n(k) >= 12 and n(k + ' split out') >= 120                                         # (fp32 outputs: module ends only)
     assert n(k) + n(k + ' split out') >= 144 and n(kb) + n(kb + ' split out') >= 32 and n(kb) >= 8 and n(kb + ' split out') >= 24
+    # layer1 (bneckx3.hip): block 0's conv3 with its downsample branch inside, and the seams conv3 + next conv1 of blocks 1 | 2 and 2 | 3
+    # (two checks each: the 256-channel block output and the next block's 64-channel conv1 output)
+    assert n('bneck_tail_ds_x3') == 1 and n('bneck_seam_x3') == 4, {k: v.get('ops') for k, v in stats.items()}
 
 
 def test_every_launch_of_the_fp16x3_engine_w32_270p(sncal, cuda):

@@ -40,12 +40,12 @@ import numpy as np
 from . import camera_math as cm
 from .pitch import GOAL_LEFT, GOAL_RIGHT, GROUND, KEEP_POINTS, TOP_GATES, pitch_points
 
-# Stopping rules of the minimisers and the handling of a failed IAC factorisation.  Default: run to convergence / drop the
-# homography camera (the build's specification, shared with csrc/solve.hip).  tools/solve_schedule_sweep.py switches them to
-# bound the UNPINNED gap to OpenCV: `opencv_stops()` = calibrateCamera's default criteria of 30 joint iterations and
-# solvePnPRefineLM's criteria (20000, 1e-5) on step and residual (SURVEY 8c notes; the damping schedule stays the build's
-# own); `iac_failure='reference'` = go on with K = I as prediction.py:514 does.
-STOP = dict(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='drop')
+# Stopping rules of the minimisers and the handling of a failed IAC factorisation (shared with csrc/solve.hip).  Default since round
+# 3 / 4: OpenCV's schedules as far as they are known (`opencv_stops()`: calibrateCamera's default criteria of 30 joint iterations,
+# solvePnPRefineLM's criteria (20000, 1e-5) on step and residual; SURVEY 8c notes) and `iac_failure='reference'` = go on with
+# K = I as prediction.py:514 does.  tools/solve_schedule_sweep.py switches them (`converged_stops()`, `iac_failure='drop'` = rounds
+# 1-3: the homography camera is unavailable) to bound the UNPINNED gap to OpenCV.
+STOP = dict(schedule='opencv', joint_iters=30, pose_iters=20000, pose_eps=1e-5, pose_res_eps=1e-5, iac_failure='reference')
 COUNTERS = dict(iac_failures=0, refine_cap_hits=0)
 FLT_EPSILON = 1.1920928955078125e-07
 DBL_EPSILON = 2.220446049250313e-16
@@ -821,7 +821,7 @@ def camera_from_homography(ids, uv, img_wh=(960, 540)):
     if not ok:
         COUNTERS['iac_failures'] += 1
         if STOP['iac_failure'] != 'reference':
-            return None      # build deviation: the reference ignores the failure flag (:514, quirk Q5) and goes on with K = I
+            return None      # rounds 1-3 (kept for the sweeps): drop the candidate; the reference ignores the failure flag (:514) and goes on with K = I
         # the reference's path: Camera() keeps calibration = eye(3), focal lengths 1, principal point (w/2, h/2) for project_point
         cam.calibration = np.eye(3)
         cam.xfocal_length = cam.yfocal_length = 1.0

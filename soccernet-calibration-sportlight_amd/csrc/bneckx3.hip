@@ -31,7 +31,7 @@ namespace sncal {
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-constexpr int NW = 8;                                  // wavefronts per workgroup
+constexpr int NW = 8;                                  // wavefronts per workgroup (12, three per SIMD, measured 8 % slower: 4.2 against 4.6 TB/s)
 constexpr int OFF_W3 = 0, OFF_W1 = BNP_W_BYTES, OFF_B3 = 2 * BNP_W_BYTES, OFF_B1 = OFF_B3 + BNP_WIDE * 4, BNP_LDS = OFF_B1 + BNP_MID * 4;
 static_assert(BNP_LDS <= 160 * 1024, "LDS");
 

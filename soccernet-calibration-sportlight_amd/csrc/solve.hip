@@ -1188,8 +1188,16 @@ __device__ int camera_from_homography(u64 mask, const Pts& p, int img_w, int img
     double H[9];
     if (!homography_ransac(g, p.X32[0], p.X32[1], p.u32, p.v32, 10.0, H)) return ST_NONE;
     double fx, fy;
-    if (!k_from_homography(H, img_w / 2.0, img_h / 2.0, fx, fy)) return ST_NONE;   // build deviation, see oracle
-    c.fx = fx; c.fy = fy; c.cx = img_w / 2.0; c.cy = img_h / 2.0; c.ppx = c.cx; c.ppy = c.cy;
+    if (k_from_homography(H, img_w / 2.0, img_h / 2.0, fx, fy)) {
+        c.fx = fx; c.fy = fy; c.cx = img_w / 2.0; c.cy = img_h / 2.0; c.ppx = c.cx; c.ppy = c.cy;
+    } else {
+        // prediction.py:514 ignores the failure flag of estimate_calibration_matrix_from_plane_homography: the Camera() keeps its
+        // initial state -- calibration = eye(3), focal lengths 1 (camera.py:33-40), principal point (w/2, h/2) for project_point -- and
+        // goes through solve_pnp / refine_camera / projection_rmse like any other.  Followed since round 4 (rounds 1-3 returned None
+        // here): the K = I camera itself never survives the rmse tests of its callers, but a solve_pnp failure under it raises, and
+        // the reference then has no camera for the frame.
+        c.fx = c.fy = 1.0; c.cx = c.cy = 0.0; c.ppx = img_w / 2.0; c.ppy = img_h / 2.0;
+    }
     if (!cam_solve_pnp(c, mask, p)) return ST_RAISE;
     cam_refine(c, mask, p);
     c.rmse = cam_rmse(c, mask, p);

@@ -571,40 +571,106 @@ __device__ __forceinline__ void pose_rows_rvec(const double* R, const double* Jl
 
 // cv::solve(A, b, DECOMP_EIG / DECOMP_SVD) for a symmetric 6x6 system: Cholesky when A is positive definite, else the minimum-norm
 // solution from a cyclic Jacobi eigen-decomposition with eigenvalues below 2 eps sum|w| dropped
-__device__ void sym_solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
-    if (chol_solve<6>(A, b, x)) return;
-    double M[6][6], V[6][6];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) { M[i][j] = A[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i + 1; j < 6; ++j) off += M[i][j] * M[i][j];
-        if (!(off > 1e-300)) break;
-        for (int pq = 0; pq < 15; ++pq) {
-            int p_ = 0, q_ = 1, c = pq;
-            for (p_ = 0; p_ < 5; ++p_) { if (c < 5 - p_) { q_ = p_ + 1 + c; break; } c -= 5 - p_; }
-            const double apq = M[p_][q_];
-            if (apq == 0.0) continue;
-            const double th = (M[q_][q_] - M[p_][p_]) / (2.0 * apq);
-            const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
-            for (int k2 = 0; k2 < 6; ++k2) { const double a = M[k2][p_], bb = M[k2][q_]; M[k2][p_] = cs * a - sn * bb; M[k2][q_] = sn * a + cs * bb; }
-            for (int k2 = 0; k2 < 6; ++k2) { const double a = M[p_][k2], bb = M[q_][k2]; M[p_][k2] = cs * a - sn * bb; M[q_][k2] = sn * a + cs * bb; }
-            for (int k2 = 0; k2 < 6; ++k2) { const double a = V[k2][p_], bb = V[k2][q_]; V[k2][p_] = cs * a - sn * bb; V[k2][q_] = sn * a + cs * bb; }
+// (The rotation indices are compile-time constants -- fully unrolled pair loop -- so that M and V live in registers: with run-time
+// indices they sat in scratch memory and one fallback solve cost tens of thousands of clocks; the slow LM runs of degenerate
+// candidates are exactly the ones that take this path every iteration.  Same operations in the same order as before.)
+struct Sym6 { bool chol; double L[6][6]; double M[6][6], V[6][6]; double thr; };
+__device__ __forceinline__ void sym_factor6(const double (&A)[6][6], Sym6& F) {
+    // Cholesky factor (chol_solve's): usable when every pivot passes
+    double dmax = A[0][0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) dmax = fmax(dmax, A[i][i]);
+    bool ok = dmax > 0;
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double d = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= F.L[j][k] * F.L[j][k];
+            if (!(d > 1e-11 * dmax)) { ok = false; d = 1.0; }
+            const double ljj = sqrt(d);
+            F.L[j][j] = ljj;
+#pragma unroll
+            for (int i = j + 1; i < 6; ++i) {
+                double s = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= F.L[i][k] * F.L[j][k];
+                F.L[i][j] = s / ljj;
+            }
         }
     }
-    double sw = 0;
-    for (int i = 0; i < 6; ++i) sw += fabs(M[i][i]);
-    const double thr = 2.0 * DBL_EPS * sw;
-    for (int i = 0; i < 6; ++i) x[i] = 0;
-    for (int e = 0; e < 6; ++e) {
-        if (!(fabs(M[e][e]) > thr)) continue;
-        double pj = 0;
-        for (int i = 0; i < 6; ++i) pj += V[i][e] * b[i];
-        pj /= M[e][e];
-        for (int i = 0; i < 6; ++i) x[i] += V[i][e] * pj;
+    F.chol = ok;
+    if (ok) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { F.M[i][j] = A[i][j]; F.V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 6; ++j) off += F.M[i][j] * F.M[i][j];
+        if (!(off > 1e-300)) break;
+#pragma unroll
+        for (int p_ = 0; p_ < 5; ++p_)
+#pragma unroll
+            for (int q_ = p_ + 1; q_ < 6; ++q_) {
+                const double apq = F.M[p_][q_];
+                if (apq != 0.0) {
+                    const double th = (F.M[q_][q_] - F.M[p_][p_]) / (2.0 * apq);
+                    const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; ++k2) { const double a = F.M[k2][p_], bb = F.M[k2][q_]; F.M[k2][p_] = cs * a - sn * bb; F.M[k2][q_] = sn * a + cs * bb; }
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; ++k2) { const double a = F.M[p_][k2], bb = F.M[q_][k2]; F.M[p_][k2] = cs * a - sn * bb; F.M[q_][k2] = sn * a + cs * bb; }
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; ++k2) { const double a = F.V[k2][p_], bb = F.V[k2][q_]; F.V[k2][p_] = cs * a - sn * bb; F.V[k2][q_] = sn * a + cs * bb; }
+                }
+            }
     }
+    double sw = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sw += fabs(F.M[i][i]);
+    F.thr = 2.0 * DBL_EPS * sw;
+}
+__device__ __forceinline__ void sym_apply6(const Sym6& F, const double (&b)[6], double (&x)[6]) {
+    if (F.chol) {
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double s = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= F.L[i][k] * y[k];
+            y[i] = s / F.L[i][i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= F.L[k][i] * x[k];
+            x[i] = s / F.L[i][i];
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        if (!(fabs(F.M[e][e]) > F.thr)) continue;
+        double pj = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pj += F.V[i][e] * b[i];
+        pj /= F.M[e][e];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] += F.V[i][e] * pj;
+    }
+}
+__device__ void sym_solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    Sym6 F;
+    sym_factor6(A, F);
+    sym_apply6(F, b, x);
 }
 
 // normal equations of the pose problem at x = [rvec, tvec]: A = J^T J, g = J^T r, S = |r|^2, rinf = |r|_inf (all wave-uniform)
@@ -679,10 +745,13 @@ __device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, cons
             nu = fmin(fmax(nu, 2.0), 10.0);
             if (lam == 0.0) {
                 double mx = DBL_EPS;
+                Sym6 F;                              // one factorisation for the six columns of the inverse
+                sym_factor6(A, F);
+#pragma unroll
                 for (int e = 0; e < 6; ++e) {
                     double unit[6] = {0, 0, 0, 0, 0, 0}, col[6];
                     unit[e] = 1.0;
-                    sym_solve6(A, unit, col);
+                    sym_apply6(F, unit, col);
                     mx = fmax(mx, fabs(col[e]));
                 }
                 lam = lc = 1.0 / mx;

@@ -20,6 +20,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
                 k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((ty,) + m2.groups()[1:])
             else:
                 k = ('headx3_fused' if 'headx3_kernel' in k else 'head_fused' if ('head_fused' in k or 'head32_kernel' in k) else
+                     'bneck_tail_ds_x3' if ('bneck_pair_kernel' in k and ('ILb1ELb0E' in k or '<true, false>' in k)) else 'bneck_seam_x3' if 'bneck_pair_kernel' in k else
                      'bblockx3_fused' if 'bblockx3_kernel' in k else 'bblock48_fused' if 'bblock48_kernel' in k else 'upsample_add' if 'upsample_add_kernel' in k else k[:48])
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         key = (r['Dispatch_Id'], k)

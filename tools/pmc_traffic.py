@@ -6,7 +6,11 @@ f, w = {}, {}
 for dd in d.split(','):          # one directory per engine (tools/round_profile.sh: fp16x3 and bf16 passes), merged
     f.update(json.load(open(os.path.join(dd, 'FETCH_SIZE', 'summary.json')))); w.update(json.load(open(os.path.join(dd, 'WRITE_SIZE', 'summary.json'))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = {'note': f'per-launch HBM bytes from PMC at sub-batch {batch} (profiles/{tag}_pmc_hbm_traffic.md)'}
+out = {}
+prev = os.path.join(root, 'profiles', 'pmc_traffic.json')
+if os.path.exists(prev):          # kernels not in these passes (the other engine's) keep their last measured value
+    out.update({k: v for k, v in json.load(open(prev)).items() if k not in ('note', 'read_factor')})
+out['note'] = f'per-launch HBM bytes from PMC at sub-batch {batch} (latest passes: profiles/{tag}_pmc_hbm_traffic.md; kernels absent from them keep their previous value)'
 rows = []
 def label(k):
     return ('headx3_fused' if 'headx3' in k else 'head_fused' if 'head32_kernel' in k or 'head_fused' in k else 'bblockx3_fused' if 'bblockx3' in k

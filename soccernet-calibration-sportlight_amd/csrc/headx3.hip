@@ -13,7 +13,9 @@
 // Why: in the fp32-class engines the head was three passes over fp32 tensors of 784 channels x 270 x 480 x 64 frames = 26 GB each
 // (per-source products 19 ms, bilinear sum 33 ms, last conv ~8 ms per 64 frames); fused, the hidden vector never leaves registers.
 // Tiling, row order (h32_row_channel), the register repack between the GEMMs and the decode-fused epilogue (per-pixel log-softmax, row
-// and column maxima of the tile) are head32.hip's; a workgroup holds 51 KB of LDS (three per CU).
+// and column maxima of the tile) are head32.hip's.  Slice pipeline (round 4): the kernel's 232 VGPRs allow two workgroups per CU, so a
+// workgroup takes 78 KB of LDS: stage-1 weights double-buffered and requested a slice ahead, stage-2 weights requested at the top of their
+// slice (they land under stage 1 + gather), a wave's gather boxes requested as soon as the wave has read the current ones.
 #include "common.hpp"
 #include "head.hpp"
 #include <vector>

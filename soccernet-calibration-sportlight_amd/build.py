@@ -30,13 +30,13 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(verbose=False, force=False, jobs=None, x3_f16=None, lib=None, obj=None):
+def build(verbose=False, force=False, jobs=None, x3_f16=None, lib=None, obj=None, extra_flags=()):
     """x3_f16=0 / 1 builds the split-arithmetic engine with bf16 / fp16 splits (default: the source's default, fp16) -- an A/B build
     goes to its own `lib` path and `obj` directory (tools/ab_build.py)."""
     global OBJ, LIB
     OBJ, LIB = obj or OBJ, lib or LIB
     hipcc = _hipcc()
-    flags = list(CXXFLAGS) + ([f'-DSNCAL_X3_F16={int(x3_f16)}'] if x3_f16 is not None else [])
+    flags = list(CXXFLAGS) + ([f'-DSNCAL_X3_F16={int(x3_f16)}'] if x3_f16 is not None else []) + list(extra_flags)
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h', '.inc'))]

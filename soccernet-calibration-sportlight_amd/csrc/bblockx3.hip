@@ -51,12 +51,13 @@ constexpr int X_PITCH = XW * PXB, X_PIECES = 34, X_PLANE = X_PIECES * 1024;     
 constexpr int M_PITCH = MW * PXB, M_PLANE = MH * M_PITCH;
 constexpr int RING_SLOTS = 4;                       // 2 x BBX_STEPS is a multiple: a step's slot is a compile-time constant
 constexpr int OFF_X = 0, OFF_M = OFF_X + 2 * X_PLANE, OFF_RING = OFF_M + 2 * M_PLANE;
-constexpr int OFF_BIAS = OFF_RING + RING_SLOTS * BBX_STEP_BYTES, OFF_CTRL = OFF_BIAS + 96 * 4, LDS_BYTES = OFF_CTRL + 64;
+constexpr int OFF_BIAS = OFF_RING + RING_SLOTS * BBX_STEP_BYTES, OFF_CTRL = OFF_BIAS + 96 * 4, LDS_BYTES = OFF_CTRL + 96;
 constexpr int NW = 8;                               // multiplying waves (two per SIMD); wave NW streams the weights, wave NW + 1 the x halos
 constexpr int J1 = (MH + NW - 1) / NW, J2 = TH / NW;                          // pixel fragments (tile rows) per wave: conv1 (at most), conv2
 constexpr int NSUB = 3 * BBX_STEPS - 1;             // sub-steps of a convolution: (cross u0, cross u1, main) per step, no cross for the zero unit
 static_assert(XH * X_PITCH <= X_PLANE && (2 * BBX_STEPS) % RING_SLOTS == 0 && TH % NW == 0 && J1 == J2 + 1 && LDS_BYTES <= 160 * 1024, "layout");
-enum { C_WREADY = 0, C_XREADY = 2, C_XFREE = 3, C_MID = 4, C_WDONE = 8 };          // C_WDONE + w: steps wave w has finished reading (a SUM over waves
+enum { C_WREADY = 0, C_XREADY = 2, C_XFREE = 3, C_MID = 4, C_TKNOWN = 5, C_WDONE = 8, C_TILE = 16 };       // C_TILE + (round & 3): the round's tile, or TILE_END
+constexpr unsigned TILE_END = 0xffffffffu;          // C_WDONE + w: steps wave w has finished reading (a SUM over waves
                                                                                        // would let seven fast waves vouch for a slow one)
 
 // One LDS-DMA piece (64 lanes x 16 bytes -> 1 KB at LDS byte address `lds_addr`) as inline assembly: hipcc's wait-count pass does not
@@ -84,18 +85,19 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned* const ctrl = reinterpret_cast<unsigned*>(smem + OFF_CTRL);
     float* const s_bias = reinterpret_cast<float*>(smem + OFF_BIAS);
-    if (tid < 16) ctrl[tid] = 0u;
+    if (tid < 24) ctrl[tid] = 0u;
     if (tid < 96) s_bias[tid] = tid < 48 ? p.b1[tid] : p.b2[tid - 48];
     __syncthreads();
 
     // tiles of this workgroup: the launch's tiles are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8); the
-    // workgroups of an XCD take consecutive tiles of its range, so neighbouring halos meet in one L2
-    const int per_xcd = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, wx = (int)blockIdx.x >> 3;
+    // workgroups of an XCD take the tiles of its range IN ORDER from a ticket counter of the XCD (p.ticket[xcd]), so neighbouring halos
+    // meet in one L2 -- and a workgroup whose CU another stream's work holds for a while (the camera solves of the previous batch)
+    // simply takes fewer tiles.  With the static deal of rounds 3 / 4 (tile t_lo + wx + round * per_xcd) such a workgroup started late
+    // and the launch lasted until it had walked its whole share: +4 % on the blocks that run beside the solves.  The halo wave takes the
+    // ticket (it is a round ahead of everybody) and publishes the tile through LDS; the last workgroup to run dry re-arms the counters.
+    const int xcd = (int)blockIdx.x & 7;
     const int n_tiles = p.N * p.tiles_y * p.tiles_x;
     const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
-    const int t0 = t_lo + wx;
-    if (t0 >= t_hi) return;
-    const int my_tiles = (t_hi - t0 + per_xcd - 1) / per_xcd;
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)smem;
     const unsigned img_twin = (unsigned)(p.H * p.W * 192);
 
@@ -105,8 +107,22 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
         // One tile's x halo per round: 34 + 34 requests that come from HBM.  It has a wave (= a request queue) of its own: requests of one
         // wave complete in order, and riding with the weight stream -- all at once, or a few per step -- the halo's HBM latency stood in
         // front of every weight step that followed it (conv2: 8k clk of MFMAs took 18k / 23k clk, phase trace).
-        for (int ti = 0; ti < my_tiles; ++ti) {
-            const int t = t0 + ti * per_xcd;
+        for (int ti = 0;; ++ti) {
+            unsigned tk = 0;
+            if (lane == 0) tk = atomicAdd(p.ticket + xcd, 1u);
+            const int t = t_lo + __builtin_amdgcn_readfirstlane((int)tk);
+            const bool dry = t >= t_hi;
+            // (slot ti & 3 last held round ti - 4; every reader is in round ti - 1 or later: the XFREE wait below)
+            publish(C_TILE + (ti & 3), dry ? TILE_END : (unsigned)t);
+            publish(C_TKNOWN, (unsigned)ti + 1u);
+            if (dry) {
+                if (lane == 0 && atomicAdd(p.ticket + 8, 1u) == gridDim.x - 1u) {     // every workgroup holds its one failing ticket
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) p.ticket[i] = 0u;
+                    __threadfence();
+                }
+                break;
+            }
             const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
             const int oy0 = ty * TH - 2, ox0 = tx * TW - 2;
             const i32x4_t rs = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_twin, img_twin);
@@ -134,7 +150,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
         // pieces of steps g - 1 and g in flight: steps <= g - 2 have landed.
         const i32x4_t rs_w1 = raw_rsrc(p.w1, BBX_W_BYTES), rs_w2 = raw_rsrc(p.w2, BBX_W_BYTES);
         unsigned g = 0;
-        for (int ti = 0; ti < my_tiles; ++ti) {
+        for (int ti = 0;; ++ti) {
+            spin_until(ctrl + C_TKNOWN, (unsigned)ti + 1u);          // (known a round ahead: the halo wave takes round ti + 1's ticket as round ti begins)
+            if (poll(ctrl + C_TILE + (ti & 3)) == TILE_END) break;
             for (int s = 0; s < 2 * BBX_STEPS; ++s, ++g) {
                 if (g >= (unsigned)RING_SLOTS) {                                        // every wave is done with the slot's previous step
                     const unsigned need = g - RING_SLOTS + 1u;
@@ -245,8 +263,11 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
     const bool tracing = p.trace != nullptr;
     auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
 
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        const int t = t0 + ti * per_xcd;
+    for (int ti = 0;; ++ti) {
+        spin_until(ctrl + C_TKNOWN, (unsigned)ti + 1u);
+        const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane((int)poll(ctrl + C_TILE + (ti & 3)));
+        if (tu == TILE_END) break;
+        const int t = (int)tu;
         const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
         const int oy0 = ty * TH, ox0 = tx * TW;
         const unsigned gs = (unsigned)ti * 2u * BBX_STEPS;
@@ -360,6 +381,7 @@ int launch_bblockx3(const BBlockX3Params& p0, hipStream_t s) {
     }
     static const char* trace_file = getenv("SNCAL_BBX_TRACE");
     if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * NW * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * NW * 64, s);
+    if (!p.ticket) { set_error("launch_bblockx3: no ticket words"); return SNCAL_ERR_ARG; }
     SNCAL_LAUNCH(bblockx3_kernel, dim3((unsigned)n_wgs), dim3(64 * (NW + 2)), (size_t)LDS_BYTES, s, p);
     SNCAL_CHECK_LAUNCH();
     if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run

@@ -23,6 +23,7 @@ struct BBlockX3Params {
     int tiles_x, tiles_y;   // filled by the launcher
     int dbg;                // tuning aid (SNCAL_BBX_DBG): 1 = drop the output stores (timing only)
     unsigned long long* trace;   // tuning aid (SNCAL_BBX_TRACE=<file>): 8 clock sums per wave, or null
+    unsigned* ticket;       // nine zeroed device words owned by the caller's stream: tile tickets per XCD [0..8), workgroups that ran dry [8] (re-armed by the kernel)
 };
 
 int launch_bblockx3(const BBlockX3Params& p, hipStream_t s);

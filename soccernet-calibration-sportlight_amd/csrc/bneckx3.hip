@@ -68,7 +68,17 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
         const float4 a = *reinterpret_cast<const float4*>(smem + off + c * 4), b = *reinterpret_cast<const float4*>(smem + off + c * 4 + 16);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     };
-    for (long long g = (long long)blockIdx.x * NW + wave; g < G; g += (long long)gridDim.x * NW) {
+    // Pixel groups are taken from a device-wide ticket counter, one per wave and round, not dealt statically: the kernel is one
+    // workgroup per CU, and a CU that another stream's work holds (the previous batch's camera solves sit on up to 16 + a few CUs for
+    // ~15 ms) starts its workgroup late -- with a static deal the launch then lasts until that workgroup has walked its whole share
+    // (measured: 1.26 -> 1.85 ms per seam beside the solves).  Tickets go out in address order, so the stream stays sequential in HBM.
+    // The ticket for the NEXT round is requested at the top of a round and read at its end.  The last wave to leave re-arms the counter.
+    auto take = [&]() -> unsigned { unsigned t = 0; if (lane == 0) t = atomicAdd(p.ticket, 1u); return t; };
+    unsigned t_next = take();
+    for (;;) {
+        const long long g = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t_next);
+        if (g >= G) break;
+        t_next = take();
         const long long px_raw = g * 32 + l31;
         const bool ok = px_raw < p.P;
         const long long px = ok ? px_raw : p.P - 1;
@@ -162,6 +172,10 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
                 }
         }
     }
+    if (lane == 0 && atomicAdd(p.ticket + 1, 1u) == gridDim.x * NW - 1u) {      // every wave holds its one failing ticket: nobody touches the counter any more
+        p.ticket[0] = 0u; p.ticket[1] = 0u;
+        __threadfence();
+    }
 }
 
 }  // namespace
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
 int launch_bneck_pair_x3(const BneckPairParams& p, int n_cus, hipStream_t s) {
     if (p.P <= 0) return SNCAL_OK;
     const bool ds = p.wds != nullptr;
+    if (!p.ticket) { set_error("launch_bneck_pair_x3: no ticket words"); return SNCAL_ERR_ARG; }
     if (ds == (p.w1 != nullptr)) { set_error("launch_bneck_pair_x3: exactly one of the next block's conv1 and the downsample branch"); return SNCAL_ERR_ARG; }
     static bool attr_done = false;
     if (!attr_done) {

@@ -166,6 +166,9 @@ struct sncal_hrnet {
     size_t events_used = 0;
     std::string last_kernel;
     double last_flops = 0, last_bytes = 0;
+    // work tickets of the persistent kernels that deal their work dynamically (bneckx3.hip, bblockx3.hip): 64 zeroed words, re-armed by the
+    // kernels themselves; launches of one network are ordered on its stream, so they share the words
+    unsigned* d_tickets = nullptr;
     // test instrumentation (sncal_hrnet_plan_tap): copies of plan tensors taken while the executor passes an op
     struct Tap { int op, tensor; void* dst; };
     std::vector<Tap> taps;
@@ -1507,6 +1510,7 @@ extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_bnp) (void)hipFree(L.d_w_bnp); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
+    if (net->d_tickets) (void)hipFree(net->d_tickets);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
@@ -1762,6 +1766,13 @@ extern "C" int sncal_hrnet_plan_tap(sncal_hrnet* net, int op_idx, int tensor_id,
     return SNCAL_OK;
 }
 
+static int ensure_tickets(sncal_hrnet* net, hipStream_t stream) {
+    if (net->d_tickets) return SNCAL_OK;
+    SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_tickets), 64 * sizeof(unsigned)));
+    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, 64 * sizeof(unsigned), stream));
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_hrnet_forward(sncal_hrnet* net, const float* d_x, int B, int H, int W, float* d_heat, float* d_kpts,
                                    int img_h, int img_w, void* d_ws, size_t ws_bytes, void* stream_) {
     return forward_impl(net, d_x, nullptr, B, H, W, d_heat, d_kpts, img_h, img_w, d_ws, ws_bytes, stream_);
@@ -1903,6 +1914,9 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                             net->n_cus = cus > 0 ? cus : 256;
                         }
+                        rc = ensure_tickets(net, stream);
+                        if (rc) return rc;
+                        bp.ticket = net->d_tickets;
                         rc = launch_bneck_pair_x3(bp, net->n_cus, stream);
                         if (net->profiling) {
                             net->last_kernel = "bneck_tail_ds_x3";
@@ -1927,6 +1941,9 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                             net->n_cus = cus > 0 ? cus : 256;
                         }
+                        rc = ensure_tickets(net, stream);
+                        if (rc) return rc;
+                        bp.ticket = net->d_tickets;
                         rc = launch_bneck_pair_x3(bp, net->n_cus, stream);
                         if (net->profiling) {
                             net->last_kernel = "bneck_seam_x3";
@@ -1953,6 +1970,9 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         bp.w1 = net->layers[op.conv].d_w_bbx; bp.b1 = net->layers[op.conv].d_bias;
                         bp.w2 = net->layers[opx->conv].d_w_bbx; bp.b2 = net->layers[opx->conv].d_bias;
                         bp.N = sb; bp.H = ti.H; bp.W = ti.W; bp.out_cstride = to.C; bp.out_coff = opx->out_coff;
+                        rc = ensure_tickets(net, stream);
+                        if (rc) return rc;
+                        bp.ticket = net->d_tickets + 16;
                         rc = launch_bblockx3(bp, stream);
                         if (net->profiling) {
                             net->last_kernel = "bblockx3_fused";

@@ -1267,8 +1267,17 @@ __device__ int camera_from_homography(u64 mask, const Pts& p, int img_w, int img
         // the reference then has no camera for the frame.
         c.fx = c.fy = 1.0; c.cx = c.cy = 0.0; c.ppx = img_w / 2.0; c.ppy = img_h / 2.0;
     }
+#ifdef SNCAL_SOLVE_TIMING
+    const unsigned long long th0 = __builtin_amdgcn_s_memtime();
+#endif
     if (!cam_solve_pnp(c, mask, p)) return ST_RAISE;
+#ifdef SNCAL_SOLVE_TIMING
+    const unsigned long long th1 = __builtin_amdgcn_s_memtime();
+#endif
     cam_refine(c, mask, p);
+#ifdef SNCAL_SOLVE_TIMING
+    if ((threadIdx.x & 63) == 0) printf("  hom wave %d: solve_pnp %llu clk refine %llu clk fx %g\n", (int)(threadIdx.x >> 6), th1 - th0, __builtin_amdgcn_s_memtime() - th1, c.fx);
+#endif
     c.rmse = cam_rmse(c, mask, p);
     return ST_OK;
 }
@@ -1281,6 +1290,23 @@ __device__ int camera_all_points(u64 mask, const Pts& p, int img_w, int img_h, C
     for (int i = 0; i < nv; ++i) total += views[i].weight * popc64(views[i].mask);
     if (!(nv > 0 && total > 6)) return ST_NONE;
     double f, R0[9], t0[3];
+#ifdef SNCAL_SOLVE_TIMING
+    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+    const bool cal_ok = calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0);
+    const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) printf("  cap wave %d npts %d nviews %d: calibrate_planes %llu clk ok %d f %g\n", (int)(threadIdx.x >> 6), popc64(mask), nv, tq1 - tq0, (int)cal_ok, cal_ok ? f : 0.0);
+    if (!cal_ok) return ST_NONE;
+    cam_from_calibration(c, f, R0, t0, img_w, img_h);
+    const bool pnp_ok = cam_solve_pnp(c, mask, p);
+    const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) printf("  cap wave %d: solve_pnp %llu clk ok %d\n", (int)(threadIdx.x >> 6), tq2 - tq1, (int)pnp_ok);
+    if (!pnp_ok) return ST_NONE;
+    if (popc64(mask) > 6 && c.fx >= 10 && c.fx <= 20000) cam_refine(c, mask, p);
+    const unsigned long long tq3 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) printf("  cap wave %d: refine %llu clk\n", (int)(threadIdx.x >> 6), tq3 - tq2);
+    c.rmse = cam_rmse(c, mask, p);
+    return ST_OK;
+#endif
     if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, img_w, img_h, f, R0, t0)) return ST_NONE;
     cam_from_calibration(c, f, R0, t0, img_w, img_h);
     if (!cam_solve_pnp(c, mask, p)) return ST_NONE;            // always runs (quirk Q2)
@@ -1515,6 +1541,66 @@ __global__ __launch_bounds__(256, 1) void voter_kernel(const float* __restrict__
     if (threadIdx.x == 0) store_camera(out + frame, st, cam);
 }
 
+// The same second half with ONE WAVEFRONT PER CAMERA (round 4).  A frame that ends without a camera walks all of iterative_voter's
+// thresholds, and every threshold costs the voter's five cameras: on voter_kernel's four waves (wave 0 owns two cameras) the bench's
+// slowest frame took 2 x 5.9 ms = the whole 11.7 ms of the launch -- eight weak points, f = 53 px, every camera 1.1 ms of
+// calibrate_planes + 0.6 ms of RANSAC PnP + 2 ms of refine_camera at the bench's 200-iteration cap.  The cameras of ALL thresholds are
+// independent of each other (prediction.py:250-256 only stops at the first threshold that yields one; what a threshold computes does
+// not depend on the thresholds before it), so they are computed side by side, threshold x camera = up to 15 wavefronts per pending
+// frame, each on the code and the inputs the serial voter gives it (identical bits), and voter_select_kernel then walks the thresholds
+// in the reference's order and keeps the first result that is not "no camera".  Wall time = the slowest single camera (3.8 ms on
+// that frame); the work of thresholds behind the deciding one is wasted CU time on a few wavefronts.
+enum { VT_HOM = 0, VT_GROUND = 1, VT_ALL = 2, VT_KEEP = 3, VT_ACC = 4, VT_TASKS = 5 };
+__global__ __launch_bounds__(64, 1) void voter_task_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts, int B,
+                                                           sncal_voter_cfg cfg, const sncal_camera* __restrict__ out, VoterShared* __restrict__ slots) {
+    const int task = (int)blockIdx.x % VT_TASKS, ti = ((int)blockIdx.x / VT_TASKS) % cfg.n_conf_threshs;
+    const int frame = (int)blockIdx.x / (VT_TASKS * cfg.n_conf_threshs);
+    if (frame >= B || out[frame].status != STATUS_PENDING) return;
+    const int lane = threadIdx.x & 63;
+    float kp[3] = {0.f, 0.f, -1.f};
+    if (lane < NPTS) {
+        const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
+        kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
+    }
+    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    Pts p;
+    load_points(kp, p);
+    p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 20000;
+    u64 mask = select_points(kp[2], cfg.conf_threshs[ti], false, 0);
+    mask = add_line_points(mask, p, lp, cfg, 1, 0);
+    VoterShared& sh = slots[(size_t)frame * cfg.n_conf_threshs + ti];
+    Cam c;
+    c.tag = SNCAL_CAM_NONE;
+    if (task == VT_HOM) {
+        const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { sh.hom = c; sh.hs = hs; }
+    } else {
+        int s = ST_NONE, slot = 0;
+        if (task == VT_GROUND) { s = camera_all_points(mask & GROUND_MASK, p, cfg.img_w, cfg.img_h, c); slot = 3; }
+        else if (task == VT_ALL) { s = camera_all_points(mask, p, cfg.img_w, cfg.img_h, c); slot = 2; }
+        else if (task == VT_KEEP) { s = camera_all_points(mask & KEEP_MASK, p, cfg.img_w, cfg.img_h, c); slot = 0; }
+        else { s = camera_accurate_points(mask, p, 5.0, cfg.img_w, cfg.img_h, c); slot = 1; }
+        if (lane == 0) { sh.cands[slot] = c; sh.st[slot] = s; }
+    }
+}
+
+// prediction.py:250-256 on the cameras voter_task_kernel left: thresholds in order, the first one whose voter returns a camera (or raises)
+// ends the frame.  One thread per frame (the selection is scalar code).
+__global__ __launch_bounds__(64) void voter_select_kernel(int B, sncal_voter_cfg cfg, const VoterShared* __restrict__ slots, sncal_camera* __restrict__ out) {
+    const int frame = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (frame >= B || out[frame].status != STATUS_PENDING) return;
+    Cam cam;
+    cam.tag = SNCAL_CAM_NONE;
+    int st = ST_NONE;
+    for (int i = 0; i < cfg.n_conf_threshs; ++i) {
+        const VoterShared& sh = slots[(size_t)frame * cfg.n_conf_threshs + i];
+        st = voter_select(cfg, sh.hs, sh.hom, sh.st, sh.cands, cam);
+        if (st != ST_NONE) break;
+    }
+    store_camera(out + frame, st, cam);
+}
+
 __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
                                                            int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out, int defer_voter) {
     const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1679,8 +1765,23 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     hipLaunchKernelGGL(calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out, defer);
     SNCAL_CHECK_LAUNCH();
     if (defer) {
-        hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
-        SNCAL_CHECK_LAUNCH();
+        // one wavefront per (frame, threshold, camera) of the pending frames, then the selection in the reference's order; the slots live in
+        // stream-ordered memory.  SNCAL_SOLVE_TASKS=0 (tuning aid / A-B reference): the four-wave voter_kernel, thresholds one after the other
+        static const bool tasks = !(getenv("SNCAL_SOLVE_TASKS") && atoi(getenv("SNCAL_SOLVE_TASKS")) == 0);
+        if (tasks) {
+            hipStream_t st = sncal::as_stream(stream);
+            VoterShared* slots = nullptr;
+            SNCAL_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&slots), (size_t)B * cfg->n_conf_threshs * sizeof(VoterShared), st));
+            hipLaunchKernelGGL(voter_task_kernel, dim3((unsigned)(B * cfg->n_conf_threshs * VT_TASKS)), dim3(64), 0, st, d_kpts, d_line_pts, B, *cfg,
+                               (const sncal_camera*)d_out, slots);
+            SNCAL_CHECK_LAUNCH();
+            hipLaunchKernelGGL(voter_select_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, B, *cfg, (const VoterShared*)slots, d_out);
+            SNCAL_CHECK_LAUNCH();
+            SNCAL_CHECK_HIP(hipFreeAsync(slots, st));
+        } else {
+            hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+            SNCAL_CHECK_LAUNCH();
+        }
     }
     return SNCAL_OK;
 }

@@ -74,10 +74,6 @@ __device__ __forceinline__ void spin_until(unsigned* p, unsigned target) {
     while ((int)(poll(p) - target) < 0) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void split4(const float (&v)[4], h16x4& hi, h16x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) X3_SPLIT(v[e], hi[e], lo[e]);
-}
 
 __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -304,12 +300,12 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
                 for (int cb = 0; cb < 3; ++cb) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = inimg ? fmaxf(acc[cb][j][e], 0.f) : 0.f;
-                    h16x4 hi, lo;
-                    split4(v, hi, lo);
+                    for (int e = 0; e < 4; ++e) v[e] = inimg ? acc[cb][j][e] : 0.f;
+                    x3u2 hi, lo;
+                    x3_split4(v, x3_lower(true), hi, lo);              // ReLU = the split's lower clamp bound
                     char* dst = smem + OFF_M + (f * MW + ln) * PXB + cb * 32 + o * 8;
-                    *reinterpret_cast<h16x4*>(dst) = hi;
-                    *reinterpret_cast<h16x4*>(dst + M_PLANE) = lo;
+                    *reinterpret_cast<x3u2*>(dst) = hi;
+                    *reinterpret_cast<x3u2*>(dst + M_PLANE) = lo;
                 }
             }
         }
@@ -339,9 +335,8 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[cb][j][e] + res[j][cb][e], 0.f);
                 if (has_tw) {
-                    h16x4 hi, lo;
-                    split4(v, hi, lo);
-                    u32x2 d0 = __builtin_bit_cast(u32x2, hi), d1 = __builtin_bit_cast(u32x2, lo);
+                    x3u2 d0, d1;
+                    x3_split4(v, x3_lower(false), d0, d1);           // (v is past the ReLU: the fp32 output needs it too)
                     asm volatile("" : "+v"(d0), "+v"(d1));
                     __builtin_amdgcn_raw_buffer_store_b64(d0, rs_tw, vt, cb * 64, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(d1, rs_tw, vt, cb * 64 + 32, 0);

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
             const float* hp = (ks < 4 ? p.h2 : p.x0) + px * BNP_MID + 8 * hi + 16 * (ks & 3);
             const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) X3_SPLIT1(v[e], bh[ks][e], bl[ks][e]);
+            x3u4 hu, lu;
+            x3_split8(v, x3_lower(false), hu, lu);
+            bh[ks] = __builtin_bit_cast(x3h8, hu); bl[ks] = __builtin_bit_cast(x3h8, lu);
         }
         f32x16 acc1[2];
         if (NEXT) {
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
                     *reinterpret_cast<float4*>(yp + 32 * mb + 16 * h + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
                 if (NEXT) {
-                    x3h8 yh, yl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) X3_SPLIT1(v[e], yh[e], yl[e]);
+                    x3u4 yhu, ylu;
+                    x3_split8(v, x3_lower(false), yhu, ylu);
+                    const x3h8 yh = __builtin_bit_cast(x3h8, yhu), yl = __builtin_bit_cast(x3h8, ylu);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) acc1[m] = mfma3(frag(OFF_W1, m * 16 + 2 * mb + h, 0), frag(OFF_W1, m * 16 + 2 * mb + h, 1), yh, yl, acc1[m]);
                 }

@@ -54,8 +54,9 @@ __device__ __forceinline__ i32x4_t raw_rsrc(const void* base, unsigned bytes) {
 }
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) X3_SPLIT1(v[e], h[e], l[e]);
+    x3u4 hu, lu;
+    x3_split8(v, x3_lower(false), hu, lu);
+    h = __builtin_bit_cast(bf16x8, hu); l = __builtin_bit_cast(bf16x8, lu);
 }
 __device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
     acc = X3_MFMA_32x32x16(al, bh, acc);
@@ -272,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
         for (int h = 0; h < 2; ++h) {
             float hv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = x3_relu_clamp(acc1[8 * h + e]);
-            bf16x8 bh, bl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) X3_SPLIT_RAW(hv[e], bh[e], bl[e]);
+            for (int e = 0; e < 8; ++e) hv[e] = acc1[8 * h + e];
+            x3u4 bhu, blu;
+            x3_split8(hv, x3_lower(true), bhu, blu);                 // ReLU + clamp + split
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bhu), bl = __builtin_bit_cast(bf16x8, blu);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + OFF_W1H + ((rb * 2 + h) * 64 + lane) * 16);

@@ -66,6 +66,53 @@ __device__ __forceinline__ float x3_relu_clamp(float v) {
 #define X3_SPLIT_RAW(v, hi, lo) do { const float x3v_ = (v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
 #define X3_SPLIT(v, hi, lo) do { const float x3v_ = ::sncal::x3_clamp(v); (hi) = (::sncal::x3h)x3v_; (lo) = (::sncal::x3h)(x3v_ - (float)(hi)); } while (0)
 
+// Two / eight values at once.  fp16 splits: per pair two v_med3_f32 (the clamp; with RELU the lower bound is 0, i.e. ReLU rides along),
+// one v_cvt_pk_f16_f32 (the hi pair) and the lo pair as v_fma_mixlo_f16 / v_fma_mixhi_f16 -- D.f16 = f16(-hi.f16 * 1.0 + x.f32) reads the
+// packed hi halves directly, so the unpack (v_cvt_f32_f16 x 2), the v_pk_add_f32 and the second v_cvt_pk of the compiler's code for
+// lo = (f16)(x - (float)hi) are two instructions: 5 VALU instructions per pair instead of 7 (9 with a separate ReLU).  x - hi is exact in
+// fp32 (both are multiples of ulp32(x), |x - hi| <= ulp16(x) / 2), so the fused form rounds the same number once: identical bits on 2^24
+// values incl. fp16 subnormals, the clamp boundary, infinities and signed zeros (tools/dev/fma_mix_probe.hip).  Epilogues are VALU work of a
+// LOADING wave beside a multiplying partner (~6-14 clk per instruction there): conv_tt_body.inc, bblockx3.hip, headx3.hip, bneckx3.hip.
+// `lob` = x3_lower(relu): the lower clamp bound as a run-time (wave-uniform) operand, so that one copy of an epilogue serves layers with
+// and without ReLU.
+__device__ __forceinline__ float x3_lower(bool relu) {
+#if SNCAL_X3_F16
+    return relu ? 0.f : -65504.f;
+#else
+    return relu ? 0.f : -__builtin_inff();
+#endif
+}
+__device__ __forceinline__ void x3_split2(float a, float b, float lob, unsigned& hi, unsigned& lo) {
+#if SNCAL_X3_F16
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const float x0 = __builtin_amdgcn_fmed3f(a, lob, 65504.f), x1 = __builtin_amdgcn_fmed3f(b, lob, 65504.f);
+    const f2_t xx = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, h2_t));
+    unsigned d = 0;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(x1));
+    lo = d;
+#else
+    typedef x3h h2_t __attribute__((ext_vector_type(2)));
+    h2_t h, l;
+    const float x0 = __builtin_amdgcn_fmed3f(a, lob, __builtin_inff()), x1 = __builtin_amdgcn_fmed3f(b, lob, __builtin_inff());
+    X3_SPLIT_RAW(x0, h[0], l[0]);
+    X3_SPLIT_RAW(x1, h[1], l[1]);
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
+#endif
+}
+typedef unsigned x3u4 __attribute__((ext_vector_type(4)));
+typedef unsigned x3u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x3_split8(const float (&v)[8], float lob, x3u4& hi, x3u4& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { unsigned h, l; x3_split2(v[2 * k], v[2 * k + 1], lob, h, l); hi[k] = h; lo[k] = l; }
+}
+__device__ __forceinline__ void x3_split4(const float (&v)[4], float lob, x3u2& hi, x3u2& lo) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { unsigned h, l; x3_split2(v[2 * k], v[2 * k + 1], lob, h, l); hi[k] = h; lo[k] = l; }
+}
+
 // host side (weight packing): the same two codes
 inline uint16_t x3_code_host(float v) {
 #if SNCAL_X3_F16

@@ -102,6 +102,19 @@ __device__ __forceinline__ void x3_split2(float a, float b, float lob, unsigned&
     hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 #endif
 }
+// The way back: hi + lo of element `half` (0 / 1) of two packed words as ONE instruction -- v_fma_mix_f32 D = lo.f16 * 1.0 + hi.f16, the
+// fp32 sum of two exactly converted halves, i.e. (float)lo + (float)hi bit for bit (3 instructions as the compiler writes it).
+template <int HALF>
+__device__ __forceinline__ float x3_join(unsigned hi_pk, unsigned lo_pk) {
+#if SNCAL_X3_F16
+    float d;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(lo_pk), "v"(hi_pk));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(lo_pk), "v"(hi_pk));
+    return d;
+#else
+    return __uint_as_float(HALF ? lo_pk & 0xffff0000u : lo_pk << 16) + __uint_as_float(HALF ? hi_pk & 0xffff0000u : hi_pk << 16);
+#endif
+}
 typedef unsigned x3u4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x3_split8(const float (&v)[8], float lob, x3u4& hi, x3u4& lo) {

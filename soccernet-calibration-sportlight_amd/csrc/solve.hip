@@ -1361,30 +1361,45 @@ __device__ u64 select_points(const float conf, double thr, bool reliable_rule, i
     return dm & KEEP_MASK;
 }
 
-// prediction.py:339-437
-__device__ int original_voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
-    u64 mask = select_points(kp[2], thr, true, cfg.reliable_thresh);
-    mask = add_line_points(mask, p, line_pts, cfg, 0, popc64(mask & GROUND_MASK));
-    Cam hom;
-    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
-    if (hs == ST_RAISE) return ST_RAISE;
-    bool have = false;
+// prediction.py:339-437, in the three pieces calibrate_kernel runs on two wavefronts (the homography camera and the calibrated camera are
+// independent solves of the same points; the reference builds them one after the other):
+//   ov_points   the selection (:345-357)                                  -> mask, and the line points in p
+//   ov_hom      camera_from_homography (:359)                             -> hs, hom
+//   ov_cal      the multi-plane calibration branch (:361-420)             -> ST_RAISE / ST_OK (a camera, refined) / ST_NONE
+//   ov_combine  the reference's order of precedence (:359-437): an exception of either half leaves, the calibrated camera wins, the
+//               homography camera is the fallback below rmse 26
+__device__ u64 ov_points(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts& p) {
+    const u64 mask = select_points(kp[2], thr, true, cfg.reliable_thresh);
+    return add_line_points(mask, p, line_pts, cfg, 0, popc64(mask & GROUND_MASK));
+}
+__device__ int ov_cal(u64 mask, const sncal_voter_cfg& cfg, const Pts& p, Cam& out) {
     View views[3];
     const int nv = build_views(mask, cfg.min_points_per_plane, false, views);
-    if (nv > 0 && popc64(mask) > cfg.min_points) {
-        double f, R0[9], t0[3];
-        if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
-        cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
-        out.tag = SNCAL_CAM_ORIGINAL;
-        have = true;
-        if (popc64(mask & GROUND_MASK) < cfg.min_points_per_plane && !cam_solve_pnp(out, mask, p)) return ST_RAISE;
-        if (!good_camera(out)) have = false;
-        else if (popc64(mask) > cfg.min_points_for_refinement) cam_refine(out, mask, p);
-    }
-    if (!have && hs == ST_OK && hom.rmse < 26) { out = hom; out.tag = SNCAL_CAM_ORIGINAL_HOM; have = true; }
-    if (!have) return ST_NONE;
+    if (!(nv > 0 && popc64(mask) > cfg.min_points)) return ST_NONE;
+    double f, R0[9], t0[3];
+    if (!calibrate_planes(p.sched, views, nv, p.X32, p.u32, p.v32, cfg.img_w, cfg.img_h, f, R0, t0)) return ST_RAISE;
+    cam_from_calibration(out, f, R0, t0, cfg.img_w, cfg.img_h);
+    out.tag = SNCAL_CAM_ORIGINAL;
+    if (popc64(mask & GROUND_MASK) < cfg.min_points_per_plane && !cam_solve_pnp(out, mask, p)) return ST_RAISE;
+    if (!good_camera(out)) return ST_NONE;
+    if (popc64(mask) > cfg.min_points_for_refinement) cam_refine(out, mask, p);
+    return ST_OK;
+}
+__device__ int ov_combine(u64 mask, const Pts& p, int hs, const Cam& hom, int cs, const Cam& cal, Cam& out) {
+    if (hs == ST_RAISE || cs == ST_RAISE) return ST_RAISE;      // (the serial order raises in the homography half first: same outcome)
+    if (cs == ST_OK) out = cal;
+    else if (hs == ST_OK && hom.rmse < 26) { out = hom; out.tag = SNCAL_CAM_ORIGINAL_HOM; }
+    else return ST_NONE;
     out.rmse = cam_rmse(out, mask, p);
     return ST_OK;
+}
+__device__ int original_voter(const float* kp, const float* line_pts, const sncal_voter_cfg& cfg, double thr, Pts p, Cam& out) {
+    const u64 mask = ov_points(kp, line_pts, cfg, thr, p);
+    Cam hom, cal;
+    const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+    if (hs == ST_RAISE) return ST_RAISE;
+    const int cs = ov_cal(mask, cfg, p, cal);
+    return ov_combine(mask, p, hs, hom, cs, cal, out);
 }
 
 // prediction.py:259-330
@@ -1496,9 +1511,9 @@ __device__ void load_points(const float* kp, Pts& p) {
     p.u32 = p.u; p.v32 = p.v;
 }
 
-// One wavefront per frame, four frames per workgroup: a solver wave owns a whole SIMD register file (512 VGPRs), so a
-// lone wave per CU would keep the co-running convolution workgroups (one wave on each SIMD) off that CU; packed, 64
-// frames block 16 CUs instead of degrading 64.  The waves of a workgroup never communicate.
+// Four wavefronts per workgroup (calibrate_kernel: four frames, or two frames x two cameras): a solver wave owns a whole SIMD register
+// file (512 VGPRs), so a lone wave per CU would keep the co-running convolution workgroups (one wave on each SIMD) off that CU; packed,
+// 64 frames block 16-32 CUs instead of degrading 64.
 constexpr int STATUS_PENDING = -1;      // iterative_voter frames whose original_voter pass found no camera: left for voter_kernel
 
 __device__ __forceinline__ void store_camera(sncal_camera* out, int st, const Cam& cam) {
@@ -1601,17 +1616,26 @@ __global__ __launch_bounds__(64) void voter_select_kernel(int B, sncal_voter_cfg
     store_camera(out + frame, st, cam);
 }
 
+// iterative_voter / original_voter (algorithms 0, 1): TWO wavefronts per frame, two frames per workgroup -- wave 2 i the homography
+// camera, wave 2 i + 1 the calibrated camera of frame i (ov_hom / ov_cal above), the even wave combines them in the reference's order
+// and goes on (pending mark, or the serial voter when the second stage is switched off).  The other algorithms: one wavefront per frame,
+// four frames per workgroup.  The launcher sizes the grid accordingly.
+struct OvHalf { Cam cam; int st; };
 __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts,
                                                            int B, sncal_voter_cfg cfg, sncal_camera* __restrict__ out, int defer_voter) {
-    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (frame >= B) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ OvHalf half[2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool paired = cfg.algorithm <= 1;
+    const int frame = paired ? (int)blockIdx.x * 2 + (wave >> 1) : (int)blockIdx.x * 4 + wave;
+    const int role = paired ? wave & 1 : 0;
+    const bool valid = frame < B;
+    if (!paired && !valid) return;
     float kp[3] = {0.f, 0.f, -1.f};
-    if (lane < NPTS) {
+    if (valid && lane < NPTS) {
         const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
         kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
     }
-    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    const float* lp = line_pts && valid ? line_pts + (size_t)frame * 90 : nullptr;
     Pts p;
     load_points(kp, p);
     p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
@@ -1619,26 +1643,41 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     Cam cam;
     cam.tag = SNCAL_CAM_NONE;
     int st = ST_NONE;
-    switch (cfg.algorithm) {
-        case 0: {   // iterative_voter, prediction.py:245-257
-            st = original_voter(kp, lp, cfg, 0.5, p, cam);
-            if (st != ST_OK && defer_voter) {
+    if (paired) {
+        u64 mask = 0;
+        Cam hom;
+        int hs = ST_NONE;
+        if (valid) {
+            mask = ov_points(kp, lp, cfg, cfg.algorithm == 0 ? 0.5 : cfg.conf_thresh, p);
+            if (role == 1) {
+                Cam cal;
+                cal.tag = SNCAL_CAM_NONE;
+                const int cs = ov_cal(mask, cfg, p, cal);
+                if (lane == 0) { half[wave >> 1].cam = cal; half[wave >> 1].st = cs; }
+            } else {
+                hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, hom);
+            }
+        }
+        __syncthreads();
+        if (!valid || role == 1) return;
+        st = ov_combine(mask, p, hs, hom, half[wave >> 1].st, half[wave >> 1].cam, cam);
+        if (cfg.algorithm == 0 && st != ST_OK) {   // iterative_voter, prediction.py:245-257
+            if (defer_voter) {
                 if (lane == 0) { store_camera(out + frame, ST_NONE, cam); out[frame].status = STATUS_PENDING; }
                 return;
             }
-            if (st != ST_OK) {
-                st = ST_NONE;
-                for (int i = 0; i < cfg.n_conf_threshs; ++i) {
-                    st = voter(kp, lp, cfg, cfg.conf_threshs[i], p, cam);
-                    if (st != ST_NONE) break;   // camera found, or an exception leaves iterative_voter
-                }
+            st = ST_NONE;
+            for (int i = 0; i < cfg.n_conf_threshs; ++i) {
+                st = voter(kp, lp, cfg, cfg.conf_threshs[i], p, cam);
+                if (st != ST_NONE) break;   // camera found, or an exception leaves iterative_voter
             }
-            break;
         }
-        case 1: st = original_voter(kp, lp, cfg, cfg.conf_thresh, p, cam); break;
-        case 2: st = voter(kp, lp, cfg, cfg.conf_thresh, p, cam); break;
-        case 3: st = opencv_calibration(kp, cfg, p, cam); break;
-        default: st = opencv_calibration_multiplane(kp, lp, cfg, p, cam); break;
+    } else {
+        switch (cfg.algorithm) {
+            case 2: st = voter(kp, lp, cfg, cfg.conf_thresh, p, cam); break;
+            case 3: st = opencv_calibration(kp, cfg, p, cam); break;
+            default: st = opencv_calibration_multiplane(kp, lp, cfg, p, cam); break;
+        }
     }
     if (lane == 0) store_camera(out + frame, st, cam);
 }
@@ -1762,7 +1801,8 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     // which 61 were done after 2.7 ms).  They are finished by a second launch that spreads the voter over four waves.
     static const bool split = !(getenv("SNCAL_SOLVE_SPLIT") && atoi(getenv("SNCAL_SOLVE_SPLIT")) == 0);      // tuning aid
     const int defer = (cfg->algorithm == 0 && split && cfg->n_conf_threshs > 0) ? 1 : 0;
-    hipLaunchKernelGGL(calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out, defer);
+    hipLaunchKernelGGL(calibrate_kernel, dim3((unsigned)(cfg->algorithm <= 1 ? (B + 1) / 2 : (B + 3) / 4)), dim3(256), 0, sncal::as_stream(stream), d_kpts,
+                       d_line_pts, B, *cfg, d_out, defer);
     SNCAL_CHECK_LAUNCH();
     if (defer) {
         // one wavefront per (frame, threshold, camera) of the pending frames, then the selection in the reference's order; the slots live in

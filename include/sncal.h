@@ -271,7 +271,11 @@ int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pt
 
 /* CameraCreator.__call__  src/models/hrnet/prediction.py:130-136 with every algorithm of :90-96.
  *   d_kpts (B,57,3) fp32 decoded keypoints   d_line_pts (B,30,3) fp32 [x,y,valid] or NULL
- *   d_out (B) sncal_camera.  Never fails per frame: status 0 == the reference's `None`. */
+ *   d_out (B) sncal_camera.  Never fails per frame: status 0 == the reference's `None`.
+ * Asynchronous on `stream`.  iterative_voter runs as stages on that stream: the original_voter pass (two wavefronts per frame: its
+ * homography camera and its calibrated camera), then, for the frames it left without a camera, one wavefront per threshold x voter
+ * camera and a selection in the reference's threshold order (prediction.py:250-256); the scratch of that stage is stream-ordered
+ * memory (hipMallocAsync / hipFreeAsync on `stream`), nothing persists between calls. */
 int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
                     sncal_camera* d_out, void* stream);
 

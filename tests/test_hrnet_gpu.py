@@ -303,3 +303,26 @@ def test_load_model_ehm_checkpoint_without_head_key(sncal, cuda, tmp_path, gold_
     assert pred.shape == (x.shape[0], 23, 2, 3)
     assert np.array_equal(pred.cpu().numpy()[..., :2], od.line_decode(g['out'], 6.0, 4.0)[..., :2])
     assert float(pred[..., 2].max()) > 0.0                            # the bug this pins returned p = 0 everywhere
+
+
+def test_ticket_dealt_kernels_give_the_same_bytes_beside_a_busy_side_stream(sncal, cuda):
+    """The layer1 seam kernel and the fused 48-channel block take their work from ticket counters (bneckx3.hip, bblockx3.hip): a
+    workgroup whose CU another stream holds starts late and takes fewer tickets.  Which workgroup computes a tile must not show in
+    the result: the same forward alone and beside a side stream that keeps CUs busy (large workgroups with all of a CU's LDS, as the
+    camera solves hold whole CUs in production), byte for byte, several times (the counters re-arm themselves between launches)."""
+    cfg = hr.load_config('hrnet_w48')
+    net = sncal.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 21, 4.0))
+    x = hr.seeded_input(6, 270, 480, 22).to(cuda)
+    heat0, kp0 = net.forward(x, want_heat=True, decode_size=(540, 960))
+    heat0, kp0 = heat0.clone(), kp0.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=cuda)
+    a = torch.randn((6144, 6144), device=cuda)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 4 * rep):
+                a = torch.tanh(a @ a * 1e-4)             # ~ms-long GEMMs with CU-filling workgroups, back to back
+        heat, kp = net.forward(x, want_heat=True, decode_size=(540, 960))
+        torch.cuda.synchronize()
+        assert torch.equal(heat, heat0) and torch.equal(kp, kp0), rep

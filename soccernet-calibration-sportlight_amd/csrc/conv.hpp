@@ -136,6 +136,17 @@ __host__ __device__ constexpr int conv_wgs_per_cu(int KS, int NI, int MI, int G)
     return (conv_nks(KS, G) * MI <= 32 && MI * NI <= 18) ? 3 : 2;
 }
 
+// Register budget of a kernel (its __launch_bounds__): the split-arithmetic variants keep more live registers per tile (both halves of the
+// B fragments, the paired main terms), and at the 168 VGPRs of three workgroups per CU the 16-fragment tiles spilled 57 registers to
+// scratch -- the 1x1 256 -> 64 convolutions of layer1 wrote 1.5 GB per launch where the output is 0.5 GB (PMC WRITE_SIZE).  They get the
+// 256-VGPR budget of two workgroups (651 -> 578 us per launch); the LDS staging stays sized by conv_wgs_per_cu (host and device agree
+// on that one).  The 12-fragment variants (MI 6 x NI 2: 32 spilled registers) are faster WITH their spills at three workgroups per CU
+// (48 against 53 us) and keep the rule.
+template <typename T>
+__host__ __device__ constexpr int conv_launch_wgs(int KS, int NI, int MI, int G) {
+    return (Elem<T>::X3 && MI * NI > 12) ? 2 : conv_wgs_per_cu(KS, NI, MI, G);
+}
+
 // workgroups per CU / epilogue staging depth of a variant (host and device agree through these)
 __host__ __device__ constexpr int conv_resident_wgs(int KS, int NI, int MI, int G) {
     return conv_wgs_per_cu(KS, NI, MI, G);
@@ -687,7 +698,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
 }
 
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
-__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, conv_launch_wgs<T>(KS, NI, MI, G)) void conv_kernel(const ConvParams p) {
     const unsigned w = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
     if (w >= p.n_work) return;
     conv_body<T, KS, STRIDE, NI, MI, G>(p, w);
@@ -707,7 +718,7 @@ struct ConvGroupParams {
 // whole XCDs to the 384-channel member, 3x the cost per item: 20 ms instead of 13), and each member keeps the
 // neighbouring-tiles-in-one-L2 order of the single launch.
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>
-__global__ __launch_bounds__(256, conv_wgs_per_cu(KS, NI, MI, G)) void conv_group_kernel(const ConvGroupParams gp) {
+__global__ __launch_bounds__(256, conv_launch_wgs<T>(KS, NI, MI, G)) void conv_group_kernel(const ConvGroupParams gp) {
     const unsigned k = blockIdx.x & 7u;
     unsigned j = blockIdx.x >> 3;
     int m = 0;

@@ -35,7 +35,9 @@ typedef enum {
     SNCAL_ERR_HIP = -2,        /* a HIP runtime call or kernel launch failed                */
     SNCAL_ERR_STATE = -3,      /* object not finalised / weights missing                    */
     SNCAL_ERR_WORKSPACE = -4,  /* caller workspace too small                                */
-    SNCAL_ERR_UNSUPPORTED = -5 /* well-formed input that this build does not handle (e.g. progressive JPEG) */
+    SNCAL_ERR_UNSUPPORTED = -5,/* well-formed input that this build does not handle (e.g. progressive JPEG) */
+    SNCAL_ERR_RANGE = -6       /* fp16x3 engine: a folded weight (finalize) or an activation (sncal_hrnet_range_status) outside what
+                                  fp16 hi + lo halves represent; the reference's fp32 predict() has no such limit: use SNCAL_F32 */
 } sncal_status;
 
 typedef enum { SNCAL_F32 = 0, SNCAL_BF16 = 1, SNCAL_FP8 = 2, SNCAL_BF16X3 = 3 } sncal_dtype;

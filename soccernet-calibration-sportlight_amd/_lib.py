@@ -151,10 +151,18 @@ def lib():
     return _lib
 
 
+class SncalRangeError(SncalError):
+    """SNCAL_ERR_RANGE: the fp16x3 engine met a folded weight (load_state_dict) or an activation (range_status) that fp16 hi + lo
+    halves do not represent; the reference's fp32 predict() has no such limit -- use dtype='fp32'."""
+
+
+ERR_RANGE = -6
+
+
 def check(status, what=''):
     if status != 0:
         msg = lib().sncal_last_error().decode(errors='replace')
-        raise SncalError(f'{what} failed with status {status}: {msg}')
+        raise (SncalRangeError if status == ERR_RANGE else SncalError)(f'{what} failed with status {status}: {msg}')
 
 
 def current_stream_ptr():

@@ -37,9 +37,10 @@ struct TTItem {                     // one output tile x one 96-channel block
 
 struct TTParams {
     TTMember m[TT_MAX_MEMBERS];
-    const TTItem* items;            // grouped by team
-    const uint32_t* team_first;     // [2 * n_wgs + 1] offsets into items
-    const uint32_t* team_stages;    // [2 * n_wgs] sum of chunks over the team's items
+    const TTItem* items;            // grouped by XCD (workgroup b runs on XCD b % 8), most expensive member first inside an XCD
+    const uint32_t* xcd_first;      // [9] offsets into items
+    unsigned* queue;                // nine zeroed device words owned by the caller's stream: next item per XCD [0..8), teams that have left [8]
+                                    // (the kernel re-arms them; launches that share the words must be ordered on one stream)
     unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null
     int ablate;                     // tuning aid (SNCAL_TT_ABLATE, timing only, results invalid): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA
 };

@@ -124,7 +124,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
-    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; uint32_t* stages = nullptr; int n_wgs = 0; };
+    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
@@ -875,7 +875,7 @@ bool tt_eligible(const sncal_hrnet& net, const Op& op, int sb);
 
 int layout(sncal_hrnet& net, int sb, int H, int W) {
     if (net.lay_sb == sb && net.lay_h == H && net.lay_w == W) return SNCAL_OK;
-    for (auto& kv : net.tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
+    for (auto& kv : net.tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); }
     net.tt_plans.clear();
     std::vector<Tensor>& T = net.tensors;
     {   // does the fused head apply?  (bf16 path; the direct tensor must already sit at head resolution)
@@ -1220,69 +1220,58 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
     }
 }
 
-// Deal the work items of the member convolutions to the 2 * n_wgs teams.  Workgroup b runs on XCD b % 8 (observed
+// The work items of the member convolutions as eight queues, one per XCD.  Workgroup b runs on XCD b % 8 (observed
 // dispatch rule, used for speed only): every member's items -- tile-major, the 96-channel blocks of a tile adjacent --
 // are cut into 8 contiguous slices, one per XCD, so that neighbouring tiles (shared halo rows) and the blocks of one
-// tile (same input) meet in one L2; inside an XCD the items go, most expensive member first, to the team with the
-// least work so far (longest-processing-time rule): the teams of a launch finish within one cheap item of each other.
-int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, int teams_per_wg = 2, int tile_h = TT_TH, int cout_blk = TT_COUT) {
+// tile (same input) meet in one L2; inside an XCD's queue the members follow each other, most expensive first
+// (longest-processing-time order: the teams, which take the next item when they finish one, end within one cheap item
+// of each other).  Rounds 2-4 dealt the items to the teams HERE (static lists); a workgroup whose CU was held by a
+// camera-solve wavefront then started when the first other workgroup had finished, and the launch lasted twice as long.
+int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, int tile_h = TT_TH, int cout_blk = TT_COUT) {
     if (!net.n_cus) {
         int dev = 0, cus = 0;
         SNCAL_CHECK_HIP(hipGetDevice(&dev));
         SNCAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         net.n_cus = cus > 0 ? cus : 256;
     }
-    const int n_wgs = net.n_cus, nteams = teams_per_wg * n_wgs;
-    std::vector<std::vector<TTItem>> per_team(nteams);
-    std::vector<uint32_t> load(nteams, 0), cost(nteams, 0);
-    // balancing cost of an item in quarter stages: its stages + a tile-boundary term (epilogue + set-up + first landing)
-    static const int boundary_q = getenv("SNCAL_TT_BOUNDARY") ? atoi(getenv("SNCAL_TT_BOUNDARY")) : 0;
-    std::vector<std::vector<int>> xcd_teams(8);
-    for (int b = 0; b < n_wgs; ++b)
-        for (int t = 0; t < teams_per_wg; ++t) xcd_teams[b % 8].push_back(teams_per_wg * b + t);
+    const int n_wgs = net.n_cus;
+    const int n_xcd = n_wgs >= 8 ? 8 : 1;                  // (fewer than 8 workgroups: every workgroup reads queue b % 8, so only queue 0.. exist)
+    std::vector<std::vector<TTItem>> per_xcd(8);
     int order[TT_MAX_MEMBERS] = {0, 1, 2};
     std::sort(order, order + n, [&](int a, int b) { return mem[a].chunks > mem[b].chunks; });
-    size_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (Interleaving the members' items, so that the memory-heavy 96-channel tiles do not all run at the tail of the launch, measured
+    // 1.4 % SLOWER than member after member: 193.3 vs 190.6 us per grouped launch; the two teams of a workgroup walking the classes in
+    // OPPOSITE order measured 1.7 % slower on the fp16x3 launches, round 4.)
     for (int oi = 0; oi < n; ++oi) {
         const TTMember& m = mem[order[oi]];
         const int tiles_y = (m.N * (m.H + 1) + tile_h - 1) / tile_h, tiles_x = (m.W + TT_TW - 1) / TT_TW, nblk = (m.cout + cout_blk - 1) / cout_blk;
         const long total = (long)tiles_y * tiles_x * nblk;
         for (long i = 0; i < total; ++i) {
-            const int x = (int)(i * 8 / total);
-            const std::vector<int>& tl = xcd_teams[x];
-            if (tl.empty()) continue;
-            size_t best = cursor[x] % tl.size();
-            for (size_t k = 0; k < tl.size(); ++k) {      // least loaded, scanning from the rotating cursor
-                const size_t cand = (cursor[x] + k) % tl.size();
-                if (cost[tl[cand]] < cost[tl[best]]) best = cand;
-            }
-            cursor[x] = best + 1;
+            const int x = n_xcd == 8 ? (int)(i * 8 / total) : 0;
             TTItem it;
             it.member = (uint16_t)order[oi]; it.nb = (uint16_t)(i % nblk);
             const long tile = i / nblk;
             it.col0 = (int32_t)(tile % tiles_x) * TT_TW; it.row0 = (int32_t)(tile / tiles_x) * tile_h; it.pad_ = 0;
-            per_team[tl[best]].push_back(it);
-            load[tl[best]] += (uint32_t)m.chunks;
-            cost[tl[best]] += (uint32_t)(4 * m.chunks + boundary_q);
+            per_xcd[x].push_back(it);
         }
     }
-    // (Interleaving the members' items inside a team, so that the memory-heavy 96-channel tiles do not all run at the tail of
-    // the launch, measured 1.4 % SLOWER than member after member: 193.3 vs 190.6 us per grouped launch.)
-    // (Letting the two teams of a workgroup walk the classes in OPPOSITE order -- one in its 96-channel items while the partner is in its
-    // 384-channel ones, so that boundary-heavy and boundary-light phases pair up -- measured 1.7 % SLOWER on the fp16x3 launches, round 4:
-    // 33.3 against 32.7 ms per step.)
     std::vector<TTItem> flat;
-    std::vector<uint32_t> first(nteams + 1, 0);
-    for (int t = 0; t < nteams; ++t) { first[t] = (uint32_t)flat.size(); flat.insert(flat.end(), per_team[t].begin(), per_team[t].end()); }
-    first[nteams] = (uint32_t)flat.size();
+    std::vector<uint32_t> first(9, 0);
+    for (int x = 0; x < 8; ++x) { first[x] = (uint32_t)flat.size(); flat.insert(flat.end(), per_xcd[x].begin(), per_xcd[x].end()); }
+    first[8] = (uint32_t)flat.size();
     if (flat.empty()) flat.push_back(TTItem{0, 0, 0, 0, 0});
     SNCAL_CHECK_HIP(hipMalloc((void**)&out.items, flat.size() * sizeof(TTItem)));
     SNCAL_CHECK_HIP(hipMalloc((void**)&out.first, first.size() * 4));
-    SNCAL_CHECK_HIP(hipMalloc((void**)&out.stages, load.size() * 4));
     SNCAL_CHECK_HIP(hipMemcpy(out.items, flat.data(), flat.size() * sizeof(TTItem), hipMemcpyHostToDevice));
     SNCAL_CHECK_HIP(hipMemcpy(out.first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
-    SNCAL_CHECK_HIP(hipMemcpy(out.stages, load.data(), load.size() * 4, hipMemcpyHostToDevice));
     out.n_wgs = n_wgs;
+    return SNCAL_OK;
+}
+
+static int ensure_tickets(sncal_hrnet* net, hipStream_t stream) {
+    if (net->d_tickets) return SNCAL_OK;
+    SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_tickets), 64 * sizeof(unsigned)));
+    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, 64 * sizeof(unsigned), stream));
     return SNCAL_OK;
 }
 
@@ -1317,11 +1306,13 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
-        const int rc = tt_build_plan(net, tp.m, n, pd, 2, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
+        const int rc = tt_build_plan(net, tp.m, n, pd, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }
-    tp.items = it->second.items; tp.team_first = it->second.first; tp.team_stages = it->second.stages;
+    tp.items = it->second.items; tp.xcd_first = it->second.first;
+    { const int rc = ensure_tickets(&net, stream); if (rc) return rc; }
+    tp.queue = net.d_tickets + 32;
     // tuning aid: SNCAL_TT_TRACE=<file> dumps the per-team phase timestamps of the LAST launch with 3 members
     // (SNCAL_TT_TRACE_CFG64=1: of the last launch of the 64-channel tile instead)
     static const char* trace_file = getenv("SNCAL_TT_TRACE");
@@ -1507,7 +1498,7 @@ extern "C" int sncal_hrnet_create(const sncal_hrnet_desc* desc, int dtype, sncal
 
 extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     if (!net) return;
-    for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); (void)hipFree(kv.second.stages); }
+    for (auto& kv : net->tt_plans) { (void)hipFree(kv.second.items); (void)hipFree(kv.second.first); }
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_bnp) (void)hipFree(L.d_w_bnp); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_tickets) (void)hipFree(net->d_tickets);
@@ -1546,6 +1537,47 @@ extern "C" int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_we
     return SNCAL_OK;
 }
 
+// The split-fp16 engine (fp16x3) carries every operand as fp16 hi + fp16 lo: 22 significand bits for |v| in [2^-3, 65504], an ABSOLUTE
+// resolution of 2^-25 below 2^-3 (lo is subnormal there), a hard clamp at +-65504 above (x3.hpp).  The reference's predict() is fp32 with
+// no such limits (src/models/hrnet/metamodel.py:127-134), and a trained checkpoint may fold a near-dead BatchNorm channel
+// (running_var ~ 0 -> scale gamma / sqrt(eps) = 316 gamma) into its weights.  So the engine refuses what it cannot represent instead of
+// clamping it silently (x3_split_host saturates): any folded weight beyond 65504, or a layer whose weights sit so low that most of its
+// weight mass has lost more than half of the 22 bits (|w| < 2^-14: hi itself is subnormal).  The caller falls back to dtype fp32
+// (load_model does it by itself and says so).  SNCAL_X3_RANGE_CHECK=0 switches the refusal off (tests of the run-time range flag).
+static int x3_range_check(const sncal_hrnet& net) {
+#if SNCAL_X3_F16
+    if (!net.x3) return SNCAL_OK;
+    static const bool off = getenv("SNCAL_X3_RANGE_CHECK") && atoi(getenv("SNCAL_X3_RANGE_CHECK")) == 0;
+    if (off) return SNCAL_OK;
+    for (const ConvLayer& L : net.layers) {
+        if (!L.is_set || L.w.empty()) continue;
+        const size_t per = L.w.size() / (size_t)L.cout;
+        double mx = 0, mass = 0, low = 0;
+        int mx_co = 0;
+        for (int co = 0; co < L.cout; ++co) {
+            const double sc = L.scale.empty() ? 1.0 : (double)L.scale[co];
+            for (size_t i = 0; i < per; ++i) {
+                const double v = std::fabs((double)L.w[(size_t)co * per + i] * sc);
+                if (!(v <= mx)) { mx = v; mx_co = co; }                   // (NaN lands here too)
+                mass += v;
+                if (v < 6.103515625e-05) low += v;                        // 2^-14: fp16's smallest normal
+            }
+        }
+        if (!(mx <= 65504.0)) {
+            set_error("fp16x3 engine: folded weight %.6g of conv %s (output channel %d, BatchNorm scale %.6g) is outside the fp16 range "
+                      "(65504): this checkpoint needs dtype='fp32'", mx, L.name.c_str(), mx_co, L.scale.empty() ? 1.0 : (double)L.scale[mx_co]);
+            return SNCAL_ERR_RANGE;
+        }
+        if (mass > 0 && low > 0.5 * mass) {
+            set_error("fp16x3 engine: %.0f %% of the folded weight mass of conv %s lies below 2^-14 (largest weight %.3g): fp16 halves keep fewer "
+                      "than 11 of fp32's 24 bits there: this checkpoint needs dtype='fp32'", 100.0 * low / mass, L.name.c_str(), mx);
+            return SNCAL_ERR_RANGE;
+        }
+    }
+#endif
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_finalize: null");
     // physical Cin of every conv = channel count of its input tensor
@@ -1566,6 +1598,9 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
             L.is_set = true;
         }
         const int rc = pack_head(*net);
+        if (rc) return rc;
+    }
+    {   const int rc = x3_range_check(*net);            // split-fp16 engine: the folded weights must live in fp16's range (SNCAL_ERR_RANGE)
         if (rc) return rc;
     }
     for (ConvLayer& L : net->layers) {
@@ -1766,9 +1801,13 @@ extern "C" int sncal_hrnet_plan_tap(sncal_hrnet* net, int op_idx, int tensor_id,
     return SNCAL_OK;
 }
 
-static int ensure_tickets(sncal_hrnet* net, hipStream_t stream) {
-    if (net->d_tickets) return SNCAL_OK;
-    SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_tickets), 64 * sizeof(unsigned)));
+// Every forward starts from zeroed ticket words on ITS stream (256 bytes): the kernels re-arm the words themselves, but a launch that
+// failed or was torn down half way (device reset by another client, a killed process sharing nothing but the driver) must not leave the
+// next forward a counter that skips or repeats work.  A network handle is single-stream: forwards of ONE handle issued on two streams
+// at once would share these words (include/sncal.h says so); use one handle per stream (the weights are small against 288 GB).
+static int rearm_tickets(sncal_hrnet* net, hipStream_t stream) {
+    const int rc = ensure_tickets(net, stream);
+    if (rc) return rc;
     SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, 64 * sizeof(unsigned), stream));
     return SNCAL_OK;
 }
@@ -1801,6 +1840,8 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
     char* ws = reinterpret_cast<char*>(d_ws);
     const Tensor& th = net->tensors[net->t_heat];
     const int C = net->desc.num_classes;
+    rc = rearm_tickets(net, stream);
+    if (rc) return rc;
     for (int b0 = 0; b0 < B; b0 += SB) {
         const int sb = std::min(SB, B - b0);
         float* heat = d_heat ? d_heat + (size_t)b0 * C * th.H * th.W : reinterpret_cast<float*>(ws + th.offset);

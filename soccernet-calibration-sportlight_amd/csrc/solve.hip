@@ -23,7 +23,10 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace {
 
@@ -1786,6 +1789,29 @@ int ensure_pitch_uploaded() {
 
 }  // namespace
 
+// Scratch of the voter's task stage (B x thresholds x VoterShared, ~0.8 KB per frame and threshold): one buffer per (device, stream),
+// grown on demand and kept for the life of the process.  Calls on one stream are ordered, so the buffer is free again when the next
+// call on that stream reaches its task stage.  Rounds 3-4 took it from hipMallocAsync / hipFreeAsync per call: with the solves of
+// several batches on several streams (pipeline.py, round 5) an allocation that wants to reuse a block freed on ANOTHER stream made
+// the HOST wait for that stream's solve -- the next forward was enqueued 164 ms late, measured (tools/dev/trace_queues.py).
+static int voter_scratch(hipStream_t st, size_t bytes, void** out) {
+    struct Buf { void* p = nullptr; size_t bytes = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    SNCAL_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = bufs[{dev, st}];
+    if (b.bytes < bytes) {
+        if (b.p) { SNCAL_CHECK_HIP(hipStreamSynchronize(st)); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+        const size_t want = std::max(bytes, (size_t)1 << 20);
+        SNCAL_CHECK_HIP(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
                                sncal_camera* d_out, void* stream) {
     SNCAL_CHECK_ARG(B >= 0 && cfg, "sncal_calibrate: bad arguments");
@@ -1806,18 +1832,19 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     SNCAL_CHECK_LAUNCH();
     if (defer) {
         // one wavefront per (frame, threshold, camera) of the pending frames, then the selection in the reference's order; the slots live in
-        // stream-ordered memory.  SNCAL_SOLVE_TASKS=0 (tuning aid / A-B reference): the four-wave voter_kernel, thresholds one after the other
+        // the stream's own scratch buffer (voter_scratch).  SNCAL_SOLVE_TASKS=0 (tuning aid / A-B reference): the four-wave voter_kernel, thresholds one after the other
         static const bool tasks = !(getenv("SNCAL_SOLVE_TASKS") && atoi(getenv("SNCAL_SOLVE_TASKS")) == 0);
         if (tasks) {
             hipStream_t st = sncal::as_stream(stream);
             VoterShared* slots = nullptr;
-            SNCAL_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&slots), (size_t)B * cfg->n_conf_threshs * sizeof(VoterShared), st));
+            {   const int rcs = voter_scratch(st, (size_t)B * cfg->n_conf_threshs * sizeof(VoterShared), reinterpret_cast<void**>(&slots));
+                if (rcs) return rcs;
+            }
             hipLaunchKernelGGL(voter_task_kernel, dim3((unsigned)(B * cfg->n_conf_threshs * VT_TASKS)), dim3(64), 0, st, d_kpts, d_line_pts, B, *cfg,
                                (const sncal_camera*)d_out, slots);
             SNCAL_CHECK_LAUNCH();
             hipLaunchKernelGGL(voter_select_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, B, *cfg, (const VoterShared*)slots, d_out);
             SNCAL_CHECK_LAUNCH();
-            SNCAL_CHECK_HIP(hipFreeAsync(slots, st));
         } else {
             hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
             SNCAL_CHECK_LAUNCH();

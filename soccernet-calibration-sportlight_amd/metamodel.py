@@ -59,7 +59,8 @@ _MODELS = {'HRNetMetaModel': HRNetMetaModel, 'EHMMetaModel': EHMMetaModel}
 
 def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str = None, **_ignored):
     """argus.load_model(path, loss=None, optimizer=None, device=...) for the two inference models.
-    dtype: None (default) = 'fp16x3', the fp32-class engine bench.py measures (fp32 tensors, split-fp16 products, fp32 accumulation):
+    dtype: None (default) = 'fp16x3' WITH a fall-back to 'fp32' when the checkpoint's folded weights do not fit the split-fp16 range
+    (SNCAL_ERR_RANGE at finalize; a warning names the layer).  'fp16x3' is the fp32-class engine bench.py measures (fp32 tensors, split-fp16 products, fp32 accumulation):
     on 2048 deep-path frames it reproduced the exact engine's keypoint indices on every usable row and its camera on every frame
     (tools/parity_large.py, profiles/r04_parity_large_*), and the reference capture's indices on the W48 golden.  'fp32' is the
     reference's own arithmetic (predict() is fp32, metamodel.py:127-134) on the exact-fp32 MFMA engine, 2.8x slower.  'bf16' / 'fp8'
@@ -74,5 +75,16 @@ def load_model(file_path, loss=None, optimizer=None, device='cuda:0', dtype: str
     params['device'] = device
     cls = _MODELS.get(state.get('model_name', 'HRNetMetaModel'), HRNetMetaModel)
     model = cls(params, dtype=dtype)
-    model.nn_module.load_state_dict(state['nn_state_dict'])
+    try:
+        model.nn_module.load_state_dict(state['nn_state_dict'])
+    except _lib.SncalRangeError as e:
+        # the default engine refuses weights that do not fit fp16 hi + lo halves (sncal_hrnet_finalize): the drop-in default must load
+        # every checkpoint the reference's fp32 predict() loads, so it falls back to the exact-fp32 engine and says so; an engine the
+        # caller asked for by name is not replaced behind their back
+        if dtype is not None:
+            raise
+        import warnings
+        warnings.warn(f'{file_path}: {e}; falling back to the exact-fp32 engine (dtype=\'fp32\', about 3x slower)')
+        model = cls(params, dtype='fp32')
+        model.nn_module.load_state_dict(state['nn_state_dict'])
     return model

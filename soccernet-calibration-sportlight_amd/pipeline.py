@@ -8,10 +8,31 @@ Streams only overlap when they sit on different hardware queues: HIP maps stream
 4) queues, and with the multi-GPU gather a third stream (RCCL's) joins; measured, it then aliases the network
 stream and the step grows from 43 to 54 ms.  Export GPU_MAX_HW_QUEUES=8 before the process touches the GPU
 (bench.py and submit.py do).
+
+Round 5: a POOL of solve streams.  At the reference's refine criterion (camera.py:116: 20000 iterations, 1e-5) one
+crawling Levenberg-Marquardt fit keeps a single wavefront busy for up to ~600 ms, and a launch ends with its slowest
+wavefront; on ONE side stream the solve of batch k + 1 queued behind that launch and the whole pipeline ran at the
+pace of the slowest fit.  Batch k now goes to solve stream k mod P (P = SOLVE_STREAMS, default 4,
+shared by every pipeline of a device), so up to P batches are being solved while the network runs on; results are
+still delivered in submission order (`join`, `cameras`, and the gather: collectives are issued in submission order
+and run in that order on RCCL's own stream).  What a crawling wavefront still costs is the CU it sits on, which is
+why the persistent convolution kernels take their work from tickets (csrc/conv_tt_body.inc, bblockx3.hip, bneckx3.hip).
 """
+import os
+
 import torch
 
 from . import _lib
+
+SOLVE_STREAMS = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS', '4')))
+_POOLS = {}      # device index -> [streams, next]: one pool per device (lanes share it: the hardware queues are few)
+
+
+def _solve_pool(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _POOLS:
+        _POOLS[key] = [[torch.cuda.Stream(device=device) for _ in range(SOLVE_STREAMS)], 0]
+    return _POOLS[key]
 
 
 class CalibrationPipeline:
@@ -28,8 +49,14 @@ class CalibrationPipeline:
         self.line_net = line_net
         self.line_sigma, self.line_scale, self.line_prob_thre = float(line_sigma), float(line_scale), float(line_prob_thre)
         self.device = net.device
-        self.solve_stream = torch.cuda.Stream(device=self.device)
+        self._pool = _solve_pool(self.device)
+        self.max_in_flight = 2 * len(self._pool[0])
         self._pending = []
+
+    def _next_solve_stream(self):
+        streams, k = self._pool
+        self._pool[1] = (k + 1) % len(streams)
+        return streams[k]
 
     def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False):
         """frames (B,3,H,W) fp32 (ToTensor's output) or (B,H,W,3) uint8 BGR (cv2.imread's / JpegDecoder.decode's
@@ -58,24 +85,26 @@ class CalibrationPipeline:
         if extra_keypoints is not None:     # produced by the caller, on whatever stream is current for them: order it too
             extra_ready = torch.cuda.Event()
             extra_ready.record(main)
-        with torch.cuda.stream(self.solve_stream):
-            self.solve_stream.wait_event(ready)
-            kpts.record_stream(self.solve_stream)
+        side = self._next_solve_stream()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            kpts.record_stream(side)
             if d_lp is not None:
-                d_lp.record_stream(self.solve_stream)
+                d_lp.record_stream(side)
             rec = self.calibrator.solve_device(kpts, d_lp)
             out = [kpts, rec]
             if extra_keypoints is not None:
-                self.solve_stream.wait_event(extra_ready)
-                extra_keypoints.record_stream(self.solve_stream)
+                side.wait_event(extra_ready)
+                extra_keypoints.record_stream(side)
                 out.append(self.calibrator.solve_device(extra_keypoints))
             if gather:
                 from .dist import pack_records, gather_records
                 out.append(gather_records(pack_records(*out)))
         done = torch.cuda.Event()
-        done.record(self.solve_stream)
+        done.record(side)
+        self.last_done = done               # completion of THIS batch's solves (submit.py drains batch k - 1 on it)
         self._pending.append(done)
-        if len(self._pending) > 4:          # bound the number of batches in flight
+        if len(self._pending) > self.max_in_flight:          # bound the number of batches in flight (oldest first: in submission order)
             self._pending.pop(0).synchronize()
         return tuple(out)
 

@@ -118,10 +118,7 @@ def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, b
             names, blobs = [n for n, _ in keep], [b for _, b in keep]
             x = dec.decode(blobs, frames[k & 1][:len(blobs)])
         out = pipe.submit(x, names=names)
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(pipe.solve_stream):
-            ev.record(pipe.solve_stream)
-        pending.append((names, out[1], ev))
+        pending.append((names, out[1], pipe.last_done))
         drain(1)                                                                    # write batch k-1 while batch k runs
     drain(0)
     pipe.join()

@@ -427,6 +427,9 @@ def main():
         raise SystemExit(f'--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU, no oversubscription)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    # everything below runs on a non-blocking stream of the bench's own, never on the legacy null stream: the pipeline's CU-masked
+    # solve streams are blocking streams (they synchronise with the null stream), see sncal_amd/pipeline.py
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     # SNCAL_BENCH_FORCE_DIST=1 (testing aid): take the multi-GPU code path -- RCCL init, the per-step all_gather on the
     # side stream, barrier, max-over-ranks -- even with one rank, so that it can be exercised on a 1-GPU box
     use_dist = world > 1 or os.environ.get('SNCAL_BENCH_FORCE_DIST') == '1'
@@ -474,7 +477,12 @@ def main():
     diag_nosolve = diag == 'nosolve'
     diag_noprof = diag == 'noprof'
 
+    step_marks = []                                      # one event per step at the head of its forward: the steady-state step time
+
     def step():
+        if L == 1 and not diag_nosolve:
+            step_marks.append(torch.cuda.Event(enable_timing=True))
+            step_marks[-1].record()
         # forward + decode on the main stream; the solve of THESE keypoints on the pipeline's side stream (it overlaps the
         # next step's convolutions); every solve is complete before the closing fence of the timed region.
         # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on the
@@ -519,11 +527,15 @@ def main():
                 m[k] += q[k]
     for n in nets:
         n.set_profiling(0 if diag_noprof else 2)
+    step_marks.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    # steady state: head of step 0's forward to head of the last step's forward; what is left of dt is the pipeline's drain -- the
+    # solve of the LAST batch has nothing to overlap with inside a timed region that must end with every solve complete
+    steady_ms = step_marks[0].elapsed_time(step_marks[-1]) / (len(step_marks) - 1) if len(step_marks) > 1 else None
     merged = {}
     for n in nets:
         for q in n.get_profile():
@@ -537,7 +549,7 @@ def main():
         np.savez(args.dump_gather, local=pack_records(last[0][0], last[0][1]).cpu().numpy(), gathered=last[0][-1].cpu().numpy(),
                  world=world, rank=rank)
     if diag:                                             # diagnosis runs print the step time only
-        print('diag', diag, round(dt / args.steps * 1e3, 3), 'ms/step')
+        print('diag', diag, round(dt / args.steps * 1e3, 3), 'ms/step', 'steady', round(steady_ms, 3) if steady_ms else None)
         return
     # solve-stage time on the decoded keypoints, measured separately after the timed region (torch events see torch's
     # current stream, which is the stream libsncal launches on)
@@ -565,9 +577,16 @@ def main():
         solver_note = {'refine_max_iters': REFINE_CAP if REFINE_CAP > 0 else 20000, 'refine_eps': 1e-5,
                        'criterion': ('DIAGNOSIS: SNCAL_BENCH_REFINE_CAP set, not the reference criterion' if REFINE_CAP > 0 else
                                      'the reference\'s own (baseline/camera.py:116 solvePnPRefineLM criteria (20000, 1e-5)) = library default'),
-                       'solve_streams': pipes[0].max_in_flight // 2,
+                       'solve_streams': pipes[0].max_in_flight // 2, 'solve_streams_cu_masked': bool(pipes[0].masked),
+                       'solve_cus_per_xcd': sncal_amd.pipeline.SOLVE_CUS_PER_XCD if pipes[0].masked else None,
                        'nosolve_ms_per_step': round(ns_ms, 3),
-                       'step_over_nosolve': round(dt / args.steps * 1e3 / ns_ms, 4)}
+                       'step_over_nosolve': round(dt / args.steps * 1e3 / ns_ms, 4),
+                       'steady_state_ms_per_step': round(steady_ms, 3) if steady_ms else None,
+                       'steady_state_over_nosolve': round(steady_ms / ns_ms, 4) if steady_ms else None,
+                       'drain_ms': round(dt * 1e3 - steady_ms * args.steps, 1) if steady_ms else None,
+                       'note': 'ms_per_step = (K steps + drain) / K: the timed region ends with every solve complete, so the last batch\'s solve '
+                               '(one crawling Levenberg-Marquardt fit of 20000 iterations sets its latency) is exposed once per run; '
+                               'steady_state = head of forward to head of forward inside the region'}
         if REFINE_CAP == 0:             # and what a 200-iteration cap (rounds 1-4) would change on these frames: solve time, cameras that move
             cc_cap = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **dict(SOLVER_KW, refine_max_iters=200))
             ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -356,6 +356,15 @@ int sncal_jpeg_decode(sncal_jpeg* dec, const unsigned char* const* data, const s
  * ---------------------------------------------------------------------------------------------- */
 int sncal_create_target(const float* d_kpts, int B, int N, float sigma, int h, int w, float* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pipeline plumbing: a stream confined to `cus_per_xcd` compute units of each XCD (for the camera solves)
+ * replaces the 16-process CPU pool of make_submit.py:25,53-54,69 (ProcessPoolExecutor workers beside the GPU loop): the solves of
+ * up to four batches run beside the network on these streams; what they may occupy is bounded by the mask instead of by a process
+ * count.  BLOCKING stream (synchronises with the legacy null stream): see csrc/api.cpp.  Destroy with sncal_stream_destroy.
+ * ---------------------------------------------------------------------------------------------- */
+int sncal_stream_create_cu_mask(int cus_per_xcd, void** stream);
+int sncal_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,8 @@ SIGNATURES = {
                                          ctypes.c_int, vp, vp]),
     'sncal_create_target': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, vp, vp]),
     'sncal_calibrate': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp]),
+    'sncal_stream_create_cu_mask': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
+    'sncal_stream_destroy': (ctypes.c_int, [vp]),
 }
 
 _lib = None

@@ -92,7 +92,8 @@ struct Tensor {
     bool split = false;          // bf16x3 engine: split twin ([16 hi | 16 lo] bf16 per 16-channel group = 4 bytes per element) of an fp32 tensor
     int twin = -1;               // index of this tensor's fp8 twin, if any
     float scale = 0.f;           // calibrated per-tensor scale of the twin: amax / 448
-    int first = -1, last = -1;   // producing / last consuming op
+    int first = -1, last = -1;   // producing / last consuming op, as the allocator sees them (extended over launch groups and fusable pairs)
+    int last_read = -1;          // the op that really reads the tensor last (what a fusion's "nobody else reads it" test asks)
     // per-run
     int H = 0, W = 0;
     size_t offset = 0, bytes = 0;
@@ -936,6 +937,28 @@ int layout(sncal_hrnet& net, int sb, int H, int W) {
         for (int s2 = 0; s2 < op.head_nsrc; ++s2) use(op.head_src[s2]);
         for (int s2 = 0; s2 < op.head_nfold; ++s2) use(op.head_fold[s2]);
         if (op.out >= 0) { if (T[op.out].first < 0) T[op.out].first = (int)i; T[op.out].last = std::max(T[op.out].last, (int)i); }
+    }
+    for (Tensor& t : T) t.last_read = t.last;
+    {   // Two consecutive convolutions of which the second reads the first one's output may run as ONE kernel (forward_impl: the fused
+        // BasicBlocks, layer1's Bottleneck seams conv3 + next conv1, block 0's downsample tail).  That kernel reads the FIRST op's inputs
+        // while it already writes the SECOND op's output, so for every such pair -- a superset of what the executor really fuses: the
+        // predicates there depend on packing and sizes -- the first op's inputs outlive the second op and the second op's output exists
+        // from the first op on.  (Until round 4 the second output was placed at step i + 1, after the first op's inputs had been
+        // released: that they never overlapped was an accident of the first-fit geometry -- ADVICE r4.)
+        int prev = -1;
+        for (size_t i = 0; i < net.ops.size(); ++i) {
+            const Op& op = net.ops[i];
+            if (!op_active(net, op)) continue;
+            if (prev >= 0 && op.type == OP_CONV && net.ops[prev].type == OP_CONV) {
+                const Op& a = net.ops[prev];
+                if (a.out >= 0 && (op.in == a.out || op.res == a.out)) {
+                    auto keep = [&](int t) { if (t >= 0 && T[t].first >= 0) T[t].last = std::max(T[t].last, (int)i); };
+                    keep(a.in); keep(a.res); keep(a.out);
+                    if (op.out >= 0 && T[op.out].first > prev) T[op.out].first = prev;
+                }
+            }
+            prev = (int)i;
+        }
     }
     {   // the members of a launch group run concurrently: a tensor one of them reads must outlive ALL of them, and their
         // outputs must all exist from the first member on
@@ -1920,7 +1943,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                             net->layers[nx.conv].d_w_bnp && net->layers[nx.conv].cout == BNP_WIDE && !net->layers[nx.conv].x3_on &&
                             net->tensors[op.in].C == BNP_MID && net->tensors[nx.in].C == BNP_MID && net->tensors[nx.out].C == BNP_WIDE &&
                             net->tensors[op.in].H == net->tensors[nx.in].H && net->tensors[op.in].W == net->tensors[nx.in].W &&
-                            net->tensors[op.out].last == (int)oi + 1) {           // nobody else reads the downsample branch
+                            net->tensors[op.out].last_read == (int)oi + 1) {      // nobody else reads the downsample branch
                             bool skip_a = false;
                             if (!producer_twin(*net, nx.out, sb, ws, &skip_a)) opd = &nx;
                         }

@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
     __shared__ OvHalf half[2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool paired = cfg.algorithm <= 1;
-    const int frame = paired ? (int)blockIdx.x * 2 + (wave >> 1) : (int)blockIdx.x * 4 + wave;
+    const int frame = paired ? (int)blockIdx.x * 2 + (wave >> 1) : (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
     const int role = paired ? wave & 1 : 0;
     const bool valid = frame < B;
     if (!paired && !valid) return;
@@ -1683,6 +1683,66 @@ __global__ __launch_bounds__(256, 1) void calibrate_kernel(const float* __restri
         }
     }
     if (lane == 0) store_camera(out + frame, st, cam);
+}
+
+// Round 5: the first pass as SINGLE-WAVE workgroups.  calibrate_kernel's paired form couples the two halves of a frame (and two frames)
+// in one 256-thread workgroup through LDS and a barrier: a workgroup of four 512-register waves needs a completely free CU, and it
+// keeps all four SIMDs until its slowest wave is through -- at the reference's refine criterion that can be a 330 ms Levenberg-Marquardt
+// crawl.  On the CU-masked solve streams of the pipeline (8 CUs, pipeline.py) the crawling waves of earlier batches sit one per CU, no
+// CU ever has four free SIMDs, and the next batch's first pass waited for them: the step went from 113 to 155 ms (measured).  Here every
+// (frame, half) is a 64-thread workgroup that needs ONE free SIMD and leaves its result in a per-frame slot; first_pass_combine_kernel
+// (one wave per frame, small) then applies the reference's order of precedence.  Same device functions on the same inputs as the
+// paired form: identical bytes (tests/test_solve_gpu.py).
+struct FirstPass { Cam hom; Cam cal; int hs; int cs; };
+__global__ __launch_bounds__(64, 1) void first_pass_task_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts, int B,
+                                                                sncal_voter_cfg cfg, FirstPass* __restrict__ fp) {
+    const int frame = (int)blockIdx.x >> 1, role = (int)blockIdx.x & 1, lane = threadIdx.x & 63;
+    if (frame >= B) return;
+    float kp[3] = {0.f, 0.f, -1.f};
+    if (lane < NPTS) {
+        const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
+        kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
+    }
+    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    Pts p;
+    load_points(kp, p);
+    p.sched = cfg.lm_schedule == 1 ? SCHED_CONVERGED : SCHED_OPENCV;
+    p.refine_iters = cfg.refine_max_iters > 0 ? cfg.refine_max_iters : 20000;
+    const u64 mask = ov_points(kp, lp, cfg, cfg.algorithm == 0 ? 0.5 : cfg.conf_thresh, p);
+    Cam c;
+    c.tag = SNCAL_CAM_NONE;
+    if (role == 1) {
+        const int cs = ov_cal(mask, cfg, p, c);
+        if (lane == 0) { fp[frame].cal = c; fp[frame].cs = cs; }
+    } else {
+        const int hs = camera_from_homography(mask, p, cfg.img_w, cfg.img_h, c);
+        if (lane == 0) { fp[frame].hom = c; fp[frame].hs = hs; }
+    }
+}
+__global__ __launch_bounds__(64) void first_pass_combine_kernel(const float* __restrict__ kpts, const float* __restrict__ line_pts, int B,
+                                                                sncal_voter_cfg cfg, const FirstPass* __restrict__ fp,
+                                                                sncal_camera* __restrict__ out, int defer_voter) {
+    const int frame = (int)blockIdx.x, lane = threadIdx.x & 63;
+    if (frame >= B) return;
+    float kp[3] = {0.f, 0.f, -1.f};
+    if (lane < NPTS) {
+        const float* src = kpts + ((size_t)frame * NPTS + lane) * 3;
+        kp[0] = src[0]; kp[1] = src[1]; kp[2] = src[2];
+    }
+    const float* lp = line_pts ? line_pts + (size_t)frame * 90 : nullptr;
+    Pts p;
+    load_points(kp, p);
+    const u64 mask = ov_points(kp, lp, cfg, cfg.algorithm == 0 ? 0.5 : cfg.conf_thresh, p);
+    Cam cam;
+    cam.tag = SNCAL_CAM_NONE;
+    const int st = ov_combine(mask, p, fp[frame].hs, fp[frame].hom, fp[frame].cs, fp[frame].cal, cam);
+    if (lane != 0) return;
+    if (defer_voter && st != ST_OK) {        // iterative_voter, prediction.py:245-257: left for the voter stage
+        store_camera(out + frame, ST_NONE, cam);
+        out[frame].status = STATUS_PENDING;
+    } else {
+        store_camera(out + frame, st, cam);
+    }
 }
 
 // stand-alone Camera.refine_camera / Camera.solve_pnp on caller-provided 3-D / 2-D matches
@@ -1789,7 +1849,7 @@ int ensure_pitch_uploaded() {
 
 }  // namespace
 
-// Scratch of the voter's task stage (B x thresholds x VoterShared, ~0.8 KB per frame and threshold): one buffer per (device, stream),
+// Scratch of the first pass (B x FirstPass) and of the voter's task stage (B x thresholds x VoterShared, ~0.8 KB each): one buffer per (device, stream),
 // grown on demand and kept for the life of the process.  Calls on one stream are ordered, so the buffer is free again when the next
 // call on that stream reaches its task stage.  Rounds 3-4 took it from hipMallocAsync / hipFreeAsync per call: with the solves of
 // several batches on several streams (pipeline.py, round 5) an allocation that wants to reuse a block freed on ANOTHER stream made
@@ -1827,26 +1887,44 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     // which 61 were done after 2.7 ms).  They are finished by a second launch that spreads the voter over four waves.
     static const bool split = !(getenv("SNCAL_SOLVE_SPLIT") && atoi(getenv("SNCAL_SOLVE_SPLIT")) == 0);      // tuning aid
     const int defer = (cfg->algorithm == 0 && split && cfg->n_conf_threshs > 0) ? 1 : 0;
-    hipLaunchKernelGGL(calibrate_kernel, dim3((unsigned)(cfg->algorithm <= 1 ? (B + 1) / 2 : (B + 3) / 4)), dim3(256), 0, sncal::as_stream(stream), d_kpts,
-                       d_line_pts, B, *cfg, d_out, defer);
-    SNCAL_CHECK_LAUNCH();
+    hipStream_t st = sncal::as_stream(stream);
+    // Every workgroup of the default path is ONE wavefront (first_pass_task_kernel above says why); SNCAL_SOLVE_WAVE_WGS=0 (tuning
+    // aid / A-B reference, also what the byte-identity test compares with): round 4's paired 256-thread calibrate_kernel
+    static const bool wave_wgs = !(getenv("SNCAL_SOLVE_WAVE_WGS") && atoi(getenv("SNCAL_SOLVE_WAVE_WGS")) == 0);
+    const bool paired = cfg->algorithm <= 1;
+    // scratch of the stream: the first pass's per-frame slots, then the voter's per-(frame, threshold) slots
+    const size_t fp_bytes = ((size_t)B * sizeof(FirstPass) + 255) & ~(size_t)255;
+    char* scratch = nullptr;
+    {   const int rcs = voter_scratch(st, fp_bytes + (size_t)B * std::max(cfg->n_conf_threshs, 1) * sizeof(VoterShared), reinterpret_cast<void**>(&scratch));
+        if (rcs) return rcs;
+    }
+    if (paired && wave_wgs && (cfg->algorithm == 1 || defer)) {
+        FirstPass* fp = reinterpret_cast<FirstPass*>(scratch);
+        hipLaunchKernelGGL(first_pass_task_kernel, dim3((unsigned)(2 * B)), dim3(64), 0, st, d_kpts, d_line_pts, B, *cfg, fp);
+        SNCAL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(first_pass_combine_kernel, dim3((unsigned)B), dim3(64), 0, st, d_kpts, d_line_pts, B, *cfg, (const FirstPass*)fp, d_out, defer);
+        SNCAL_CHECK_LAUNCH();
+    } else if (paired) {
+        hipLaunchKernelGGL(calibrate_kernel, dim3((unsigned)((B + 1) / 2)), dim3(256), 0, st, d_kpts, d_line_pts, B, *cfg, d_out, defer);
+        SNCAL_CHECK_LAUNCH();
+    } else {                                 // voter / opencv_calibration(_multiplane): one wavefront per frame, no coupling between frames
+        const int wpw = wave_wgs ? 1 : 4;
+        hipLaunchKernelGGL(calibrate_kernel, dim3((unsigned)((B + wpw - 1) / wpw)), dim3(64 * wpw), 0, st, d_kpts, d_line_pts, B, *cfg, d_out, defer);
+        SNCAL_CHECK_LAUNCH();
+    }
     if (defer) {
-        // one wavefront per (frame, threshold, camera) of the pending frames, then the selection in the reference's order; the slots live in
-        // the stream's own scratch buffer (voter_scratch).  SNCAL_SOLVE_TASKS=0 (tuning aid / A-B reference): the four-wave voter_kernel, thresholds one after the other
+        // one wavefront per (frame, threshold, camera) of the pending frames, then the selection in the reference's order.
+        // SNCAL_SOLVE_TASKS=0 (tuning aid / A-B reference): the four-wave voter_kernel, thresholds one after the other
         static const bool tasks = !(getenv("SNCAL_SOLVE_TASKS") && atoi(getenv("SNCAL_SOLVE_TASKS")) == 0);
         if (tasks) {
-            hipStream_t st = sncal::as_stream(stream);
-            VoterShared* slots = nullptr;
-            {   const int rcs = voter_scratch(st, (size_t)B * cfg->n_conf_threshs * sizeof(VoterShared), reinterpret_cast<void**>(&slots));
-                if (rcs) return rcs;
-            }
+            VoterShared* slots = reinterpret_cast<VoterShared*>(scratch + fp_bytes);
             hipLaunchKernelGGL(voter_task_kernel, dim3((unsigned)(B * cfg->n_conf_threshs * VT_TASKS)), dim3(64), 0, st, d_kpts, d_line_pts, B, *cfg,
                                (const sncal_camera*)d_out, slots);
             SNCAL_CHECK_LAUNCH();
             hipLaunchKernelGGL(voter_select_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, B, *cfg, (const VoterShared*)slots, d_out);
             SNCAL_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, sncal::as_stream(stream), d_kpts, d_line_pts, B, *cfg, d_out);
+            hipLaunchKernelGGL(voter_kernel, dim3(B), dim3(256), 0, st, d_kpts, d_line_pts, B, *cfg, d_out);
             SNCAL_CHECK_LAUNCH();
         }
     }

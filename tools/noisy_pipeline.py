@@ -34,6 +34,8 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
     dev = torch.device('cuda:0')
+    if os.environ.get('SNCAL_NULL_STREAM') != '1':        # off the null stream: the condition for the CU-masked solve streams (pipeline.py)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     B = 64
     steps = N // B
     sd = sncal_amd.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True)
@@ -61,11 +63,12 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3, outs
 
-    res = {'frames_noisy': N, 'steps': steps, 'batch': B, 'solve_streams': pipe.max_in_flight // 2,
+    res = {'frames_noisy': N, 'steps': steps, 'batch': B, 'solve_streams': pipe.max_in_flight // 2, 'cu_masked': None,
            'refine_max_iters': cc.refine_max_iters, 'criterion': 'reference (camera.py:116)' if cc.refine_max_iters == 20000 else 'capped (diagnosis)'}
     res['nosolve_ms_per_step'], _ = run(False, False)
     res['bench_step_ms'], _ = run(True, False)
     res['noisy_step_ms'], outs = run(True, True)
+    res['cu_masked'] = bool(pipe.masked)
     res['nosolve_ms_per_step_again'], _ = run(False, False)
     ns = min(res['nosolve_ms_per_step'], res['nosolve_ms_per_step_again'])
     res['bench_step_over_nosolve'] = res['bench_step_ms'] / ns

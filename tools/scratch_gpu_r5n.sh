@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5n_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r5n_pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r5n_bench.json 2> gpurun_out/r5n_bench.err; echo "bench rc=$?"; tail -3 gpurun_out/r5n_bench.err
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r5n_bench.json'))
+print('bench', d['value'], d['ms_per_step'], json.dumps(d['config']['solver']), d['roofline']['avg_launch_us'], d['roofline']['frac'])
+print('parity', d.get('parity', {}).get('index_agreement'), d.get('parity', {}).get('frames_rmse_rel_delta_le_1e-4'), d.get('parity', {}).get('cameras_both'))
+print('fp32', d.get('fp32', {}).get('value'), d.get('fp32', {}).get('steps'), 'lanes2', d.get('lanes2', {}).get('value'), 'bf16', d.get('bf16', {}).get('value'))
+print('cpu', json.dumps(d.get('cpu_baseline')))
+PY

@@ -124,8 +124,22 @@ int sncal_hrnet_conv_info(const sncal_hrnet* net, int idx, char* name, int name_
  * = the eval-mode BatchNorm folded to y = conv(x)*scale + shift (scale NULL => 1). */
 int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_weight, const float* h_scale,
                          const float* h_shift);
-/* Pack + upload all weights (synchronous).  Every conv must have been set. */
+/* Pack + upload all weights (synchronous).  Every conv must have been set.
+ * SNCAL_BF16X3 built with fp16 halves ("fp16x3", the default engine) carries every operand as fp16 hi + lo: exact to 2^-22 relative for
+ * |v| in [2^-3, 65504], to 2^-25 absolute below, CLAMPED at +-65504 above.  The reference's predict() is plain fp32 with no such limits
+ * (src/models/hrnet/metamodel.py:127-134), so the engine guards both ends of the clamp:
+ *   here      SNCAL_ERR_RANGE when a folded weight (w * gamma / sqrt(var + eps)) exceeds 65504 in magnitude, is not finite, or when most of
+ *             a layer's weight mass lies below 2^-14 (fp16's smallest normal: the halves keep fewer than 11 bits there); the message
+ *             names the layer.  Callers fall back to SNCAL_F32 (the host mirror's load_model does so by itself, with a warning);
+ *   forward   every kernel that splits activations counts the wavefronts that met |v| > 65504: sncal_hrnet_range_status below.
+ * A network handle is SINGLE-STREAM: forwards of one handle on two streams at once would share its work-ticket words. */
 int sncal_hrnet_finalize(sncal_hrnet* net);
+/* Range flag of the split-fp16 engine since the last clear: *overflow = wavefronts that split (and clamped) an activation beyond +-65504,
+ * *nonfinite = workgroups of the input layout kernel that met a NaN / infinite frame value.  Returns SNCAL_OK when both are zero,
+ * SNCAL_ERR_RANGE otherwise (sncal_last_error says what to do: such forwards are not the reference's fp32 result).  Synchronises
+ * `stream`; clear != 0 re-arms the counters.  Engines without the clamp (SNCAL_F32, SNCAL_BF16, SNCAL_FP8, the bf16x3 build) report zeros.
+ * No reference counterpart: the reference computes in fp32 (metamodel.py:127-134) and cannot overflow where this engine can. */
+int sncal_hrnet_range_status(sncal_hrnet* net, unsigned* overflow, unsigned* nonfinite, int clear, void* stream);
 
 /* Output spatial size and workspace bytes for a (B,3,H,W) input. */
 int sncal_hrnet_output_size(const sncal_hrnet* net, int H, int W, int* out_h, int* out_w);

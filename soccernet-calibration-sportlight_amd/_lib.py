@@ -89,6 +89,7 @@ SIGNATURES = {
                                              ctypes.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     'sncal_hrnet_set_conv': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     'sncal_hrnet_finalize': (ctypes.c_int, [vp]),
+    'sncal_hrnet_range_status': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.c_int, vp]),
     'sncal_hrnet_output_size': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
     'sncal_hrnet_workspace': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.POINTER(ctypes.c_size_t)]),

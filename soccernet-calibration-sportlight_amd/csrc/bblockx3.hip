@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
 
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool tracing = p.trace != nullptr;
+    float amax = 0.f;                                  // range tracker of the mid and output splits (x3.hpp)
     auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
 
     for (int ti = 0;; ++ti) {
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = inimg ? acc[cb][j][e] : 0.f;
                     x3u2 hi, lo;
-                    x3_split4(v, x3_lower(true), hi, lo);              // ReLU = the split's lower clamp bound
+                    x3_split4(v, x3_lower(true), hi, lo, amax);        // ReLU = the split's lower clamp bound
                     char* dst = smem + OFF_M + (f * MW + ln) * PXB + cb * 32 + o * 8;
                     *reinterpret_cast<x3u2*>(dst) = hi;
                     *reinterpret_cast<x3u2*>(dst + M_PLANE) = lo;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[cb][j][e] + res[j][cb][e], 0.f);
                 if (has_tw) {
                     x3u2 d0, d1;
-                    x3_split4(v, x3_lower(false), d0, d1);           // (v is past the ReLU: the fp32 output needs it too)
+                    x3_split4(v, x3_lower(false), d0, d1, amax);     // (v is past the ReLU: the fp32 output needs it too)
                     asm volatile("" : "+v"(d0), "+v"(d1));
                     __builtin_amdgcn_raw_buffer_store_b64(d0, rs_tw, vt, cb * 64, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(d1, rs_tw, vt, cb * 64 + 32, 0);
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
         lap(5);
         tsum[7] += 1;
     }
+    x3_report(amax, p.range);
     if (tracing && lane == 0)
         for (int k = 0; k < 8; ++k) p.trace[((size_t)blockIdx.x * NW + wave) * 8 + k] = tsum[k];
 }

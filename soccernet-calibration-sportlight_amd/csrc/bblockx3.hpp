@@ -23,6 +23,7 @@ struct BBlockX3Params {
     int tiles_x, tiles_y;   // filled by the launcher
     int dbg;                // tuning aid (SNCAL_BBX_DBG): 1 = drop the output stores (timing only)
     unsigned long long* trace;   // tuning aid (SNCAL_BBX_TRACE=<file>): 8 clock sums per wave, or null
+    unsigned* range;        // fp16x3: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
     unsigned* ticket;       // nine zeroed device words owned by the caller's stream: tile tickets per XCD [0..8), workgroups that ran dry [8] (re-armed by the kernel)
 };
 

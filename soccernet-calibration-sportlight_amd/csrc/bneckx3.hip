@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
     // ~15 ms) starts its workgroup late -- with a static deal the launch then lasts until that workgroup has walked its whole share
     // (measured: 1.26 -> 1.85 ms per seam beside the solves).  Tickets go out in address order, so the stream stays sequential in HBM.
     // The ticket for the NEXT round is requested at the top of a round and read at its end.  The last wave to leave re-arms the counter.
+    float amax = 0.f;                                  // range tracker (x3.hpp)
     auto take = [&]() -> unsigned { unsigned t = 0; if (lane == 0) t = atomicAdd(p.ticket, 1u); return t; };
     unsigned t_next = take();
     for (;;) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
             const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             x3u4 hu, lu;
-            x3_split8(v, x3_lower(false), hu, lu);
+            x3_split8(v, x3_lower(false), hu, lu);          // (inputs: tracked by the kernels that wrote them)
             bh[ks] = __builtin_bit_cast(x3h8, hu); bl[ks] = __builtin_bit_cast(x3h8, lu);
         }
         f32x16 acc1[2];
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = x3_relu(acc[8 * h + e] + rr[e]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) x3_track(amax, v[e], v[e + 1]);      // every OUTPUT is tracked where it is produced (x3.hpp)
                 if (ok) {
                     *reinterpret_cast<float4*>(yp + 32 * mb + 16 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(yp + 32 * mb + 16 * h + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -168,11 +171,14 @@ __global__ __launch_bounds__(64 * NW, 1) void bneck_pair_kernel(const BneckPairP
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = x3_relu(acc1[m][8 * h + e]);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) x3_track(amax, v[e], v[e + 1]);
                     *reinterpret_cast<float4*>(op + 32 * m + 16 * h) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(op + 32 * m + 16 * h + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
         }
     }
+    x3_report(amax, p.range);
     if (lane == 0 && atomicAdd(p.ticket + 1, 1u) == gridDim.x * NW - 1u) {      // every wave holds its one failing ticket: nobody touches the counter any more
         p.ticket[0] = 0u; p.ticket[1] = 0u;
         __threadfence();

@@ -25,6 +25,7 @@ struct BneckPairParams {
     const void* wds;     // bnp_pack_weights of downsample.0 (256 x 64)
     const float* bds;    // 256
     long long P;         // pixels = N * H * W (a 1x1 convolution does not see the image structure)
+    unsigned* range;     // fp16x3: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
     unsigned* ticket;    // two zeroed device words owned by the caller's stream: [0] pixel-group tickets, [1] waves that have left (the kernel re-arms both)
 };
 

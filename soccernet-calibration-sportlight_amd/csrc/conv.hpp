@@ -89,6 +89,7 @@ struct ConvParams {
     int ablate;                      // tuning aid: bit0 skip MFMA phase, bit1 skip DMA, bit2 skip weight DMA, bit3 skip halo DMA (results invalid)
     int epi_lds;                     // 1: transpose the output tile through LDS for 16-byte coalesced stores
     unsigned long long* trace;       // tuning aid (SNCAL_CONV_TRACE): 16 timestamps per workgroup, or null
+    unsigned* range;                 // x3_t only: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
     void* out_twin;                  // x3_t only: split twin of the (dense, out_coff 0) output for the next two-team convolution, or null;
                                      // out may then be null (nobody reads the fp32 form)
 };
@@ -176,6 +177,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
     constexpr int SLOTS = PS / 16;
     constexpr int ESIZE = 16 / GE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] float amax = 0.f;       // x3_t: range tracker of the input and twin splits (x3.hpp)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,6 +529,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 }
             }
             stamp(15);
+            if constexpr (Elem<T>::X3) x3_report(amax, p.range);
             return;
         }
     }
@@ -620,6 +623,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                         }
                         u32x4 ov = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                         if constexpr (Elem<T>::X3) {
+                            x3_track(amax, v[0], v[1]); x3_track(amax, v[2], v[3]);      // every OUTPUT is tracked where it is produced (x3.hpp)
                             if (has_twin) {        // wave-uniform: [16 hi | 16 lo] bf16 per pixel and 16-channel group, this lane's 4 channels are 8 + 8 bytes
                                 x3h4 th, tl;
 #pragma unroll
@@ -642,6 +646,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                 }
                 if constexpr (!PRE_ALL) __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (Elem<T>::X3) x3_report(amax, p.range);
             return;
         }
     }
@@ -672,6 +677,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
             }
             if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             if constexpr (Elem<T>::X3) {
+                x3_track(amax, v0, v1); x3_track(amax, v2, v3);              // every OUTPUT is tracked where it is produced (x3.hpp)
                 // [16 hi | 16 lo] bf16 per pixel and 16-channel group (conv_tt_body.inc): this lane's 4 channels are 8 + 8 bytes
                 if (p.out_twin) {
                     const float v[4] = {v0, v1, v2, v3};
@@ -695,6 +701,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
             }
         }
     }
+    if constexpr (Elem<T>::X3) x3_report(amax, p.range);
 }
 
 template <typename T, int KS, int STRIDE, int NI, int MI, int G>

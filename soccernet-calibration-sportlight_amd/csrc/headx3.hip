@@ -68,6 +68,7 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, cons
 template <int DEC>
 __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
     const unsigned long long t_begin = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    float amax = 0.f;                                  // range tracker of the hidden vector (x3.hpp; the inputs were tracked by their producers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] = acc1[8 * h + e];
             x3u4 bhu, blu;
-            x3_split8(hv, x3_lower(true), bhu, blu);                 // ReLU + clamp + split
+            x3_split8(hv, x3_lower(true), bhu, blu, amax);           // ReLU + clamp + split
             const bf16x8 bh = __builtin_bit_cast(bf16x8, bhu), bl = __builtin_bit_cast(bf16x8, blu);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
             asm volatile("s_barrier" ::: "memory");               // everyone's; and everyone is done with slice q
         }
     }
+    x3_report(amax, p.range);
     if (tracing && threadIdx.x == 0 && blockIdx.x % 97 == 0)
         for (int k = 0; k < 6; ++k) p.trace[(size_t)(blockIdx.x / 97) * 8 + k] = tsum[k];
     if constexpr (DEC) {

@@ -170,6 +170,9 @@ struct sncal_hrnet {
     // work tickets of the persistent kernels that deal their work dynamically (bneckx3.hip, bblockx3.hip): 64 zeroed words, re-armed by the
     // kernels themselves; launches of one network are ordered on its stream, so they share the words
     unsigned* d_tickets = nullptr;
+    // range flag of the split-fp16 engine (x3.hpp x3_report): [0] wavefronts that split a value beyond +-65504, [1] workgroups of the
+    // layout kernel that met a NaN / infinite input value.  Sticky until sncal_hrnet_range_status(clear = 1); allocated at finalize
+    unsigned* d_range = nullptr;
     // test instrumentation (sncal_hrnet_plan_tap): copies of plan tensors taken while the executor passes an op
     struct Tap { int op, tensor; void* dst; };
     std::vector<Tap> taps;
@@ -1054,6 +1057,7 @@ int prepare_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, ConvParams& p
     const Tensor& ti = net.tensors[op.in];
     const Tensor& to = net.tensors[op.out];
     memset(&p, 0, sizeof(p));
+    p.range = net.d_range;
     p.in = ws + ti.offset; p.out = ws + to.offset;
     p.res = op.res >= 0 ? ws + net.tensors[op.res].offset : nullptr;
     p.w = L.d_w; p.bias = L.d_bias;
@@ -1302,6 +1306,7 @@ static int ensure_tickets(sncal_hrnet* net, hipStream_t stream) {
 int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* ws, hipStream_t stream) {
     TTParams tp;
     memset(&tp, 0, sizeof(tp));
+    tp.range = net.d_range;
     const bool fp8 = net.layers[ops[0].conv].fp8_on, x3 = net.layers[ops[0].conv].x3_on;
     const sncal::LaunchEvents armed = sncal::launch_events();        // the profiling event pair belongs to the convolution launch,
     sncal::launch_events() = sncal::LaunchEvents{};                  // not to the calibration / quantisation helpers in front of it
@@ -1313,7 +1318,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         }
         if (x3 && !twin_written_by_producer(net, ops[i].in, sb)) {       // bf16x3: the fp32 input's split twin, unless its producer wrote it
             const Tensor& ti = net.tensors[ops[i].in];
-            const int rc = launch_split_f32(ws + ti.offset, ws + net.tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream);
+            const int rc = launch_split_f32(ws + ti.offset, ws + net.tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream, net.d_range);
             if (rc) return rc;
         }
         if (fp8 && !twin_written_by_producer(net, ops[i].in, sb)) {      // first fp8 conv of a chain: quantise its input here
@@ -1525,6 +1530,7 @@ extern "C" void sncal_hrnet_destroy(sncal_hrnet* net) {
     for (ConvLayer& L : net->layers) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_bias) (void)hipFree(L.d_bias); if (L.d_w_tt) (void)hipFree(L.d_w_tt); if (L.d_w8) (void)hipFree(L.d_w8); if (L.d_w_x3) (void)hipFree(L.d_w_x3); if (L.d_w_bbx) (void)hipFree(L.d_w_bbx); if (L.d_w_bnp) (void)hipFree(L.d_w_bnp); if (L.d_oscale) (void)hipFree(L.d_oscale); }
     for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     if (net->d_tickets) (void)hipFree(net->d_tickets);
+    if (net->d_range) (void)hipFree(net->d_range);
     if (net->d_amax) (void)hipFree(net->d_amax);
     for (void* q : {net->d_hw0, net->d_hw1, net->d_hw0_32, net->d_hw1_32, net->d_hw0_32l, net->d_hw1_32l, (void*)net->d_hb0, (void*)net->d_hb1}) if (q) (void)hipFree(q);
     delete net;
@@ -1577,16 +1583,18 @@ static int x3_range_check(const sncal_hrnet& net) {
         const size_t per = L.w.size() / (size_t)L.cout;
         double mx = 0, mass = 0, low = 0;
         int mx_co = 0;
-        for (int co = 0; co < L.cout; ++co) {
+        bool outside = false;                                             // a folded weight beyond the range, infinite or NaN
+        for (int co = 0; co < L.cout && !outside; ++co) {
             const double sc = L.scale.empty() ? 1.0 : (double)L.scale[co];
             for (size_t i = 0; i < per; ++i) {
                 const double v = std::fabs((double)L.w[(size_t)co * per + i] * sc);
-                if (!(v <= mx)) { mx = v; mx_co = co; }                   // (NaN lands here too)
+                if (!(v <= 65504.0)) { mx = v; mx_co = co; outside = true; break; }
+                if (v > mx) { mx = v; mx_co = co; }
                 mass += v;
                 if (v < 6.103515625e-05) low += v;                        // 2^-14: fp16's smallest normal
             }
         }
-        if (!(mx <= 65504.0)) {
+        if (outside) {
             set_error("fp16x3 engine: folded weight %.6g of conv %s (output channel %d, BatchNorm scale %.6g) is outside the fp16 range "
                       "(65504): this checkpoint needs dtype='fp32'", mx, L.name.c_str(), mx_co, L.scale.empty() ? 1.0 : (double)L.scale[mx_co]);
             return SNCAL_ERR_RANGE;
@@ -1644,7 +1652,33 @@ extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
         if (rc) return rc;
         std::vector<float>().swap(L.w);
     }
+    if (net->x3 && !net->d_range) {
+        SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_range), 2 * sizeof(unsigned)));
+        SNCAL_CHECK_HIP(hipMemset(net->d_range, 0, 2 * sizeof(unsigned)));
+    }
     net->finalized = true;
+    return SNCAL_OK;
+}
+
+// The run-time half of the fp16 range guard (the load-time half is x3_range_check): how many wavefronts have split an activation beyond
+// +-65504 (x3.hpp: the value was clamped, the results of those forwards are NOT the reference's) and how many workgroups met a NaN /
+// infinite input value, since the counters were last cleared.  Synchronises `stream`.  Engines without the clamp report zeros.
+extern "C" int sncal_hrnet_range_status(sncal_hrnet* net, unsigned* overflow, unsigned* nonfinite, int clear, void* stream_) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_range_status: null net");
+    unsigned h[2] = {0u, 0u};
+    if (net->d_range) {
+        hipStream_t stream = as_stream(stream_);
+        SNCAL_CHECK_HIP(hipMemcpyAsync(h, net->d_range, sizeof(h), hipMemcpyDeviceToHost, stream));
+        if (clear) SNCAL_CHECK_HIP(hipMemsetAsync(net->d_range, 0, sizeof(h), stream));
+        SNCAL_CHECK_HIP(hipStreamSynchronize(stream));
+    }
+    if (overflow) *overflow = h[0];
+    if (nonfinite) *nonfinite = h[1];
+    if (h[0] || h[1]) {
+        set_error("fp16x3 engine: %u wavefront(s) split an activation beyond the fp16 range (clamped to +-65504) and %u workgroup(s) met a NaN / infinite "
+                  "input value since the last check: these forwards are not the reference's fp32 result -- use dtype fp32 for this checkpoint / input", h[0], h[1]);
+        return SNCAL_ERR_RANGE;
+    }
     return SNCAL_OK;
 }
 
@@ -1897,7 +1931,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
             switch (op.type) {
                 case OP_INPUT:
                     if (d_x8) rc = launch_u8hwc_to_nhwc(net->dtype, d_x8 + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, H, W, stream);
-                    else rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream);
+                    else rc = launch_nchw_to_nhwc(net->dtype, d_x + (size_t)b0 * 3 * H * W, ws + net->tensors[op.out].offset, sb, 3, H, W, stream, net->d_range ? net->d_range + 1 : nullptr);
                     break;
                 case OP_CONV: {
                     if (op.launch_group >= 0) {              // same-depth convs of the parallel branches: one grouped launch
@@ -1966,6 +2000,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         const Tensor& t_y = net->tensors[opd->out];
                         BneckPairParams bp;
                         memset(&bp, 0, sizeof(bp));
+                        bp.range = net->d_range;
                         bp.h2 = reinterpret_cast<const float*>(ws + net->tensors[opd->in].offset);
                         bp.x0 = reinterpret_cast<const float*>(ws + net->tensors[op.in].offset);
                         bp.y = reinterpret_cast<float*>(ws + t_y.offset);
@@ -1992,6 +2027,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         const Tensor& t_y = net->tensors[op.out];
                         BneckPairParams bp;
                         memset(&bp, 0, sizeof(bp));
+                        bp.range = net->d_range;
                         bp.h2 = reinterpret_cast<const float*>(ws + net->tensors[op.in].offset);
                         bp.res = reinterpret_cast<const float*>(ws + net->tensors[op.res].offset);
                         bp.y = reinterpret_cast<float*>(ws + t_y.offset);
@@ -2021,12 +2057,13 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         const sncal::LaunchEvents armed = sncal::launch_events();
                         sncal::launch_events() = sncal::LaunchEvents{};
                         if (!twin_written_by_producer(*net, op.in, sb)) {         // the fp32 input's split twin, unless its producer wrote it
-                            rc = launch_split_f32(ws + ti.offset, ws + net->tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream);
+                            rc = launch_split_f32(ws + ti.offset, ws + net->tensors[ti.twin].offset, (size_t)sb * ti.H * ti.W * ti.C, stream, net->d_range);
                             if (rc) return rc;
                         }
                         sncal::launch_events() = armed;
                         BBlockX3Params bp;
                         memset(&bp, 0, sizeof(bp));
+                        bp.range = net->d_range;
                         bp.x = ws + net->tensors[ti.twin].offset;
                         const bool twin_out = to.twin >= 0 && net->tensors[to.twin].first >= 0 && twin_written_by_producer(*net, opx->out, sb);
                         bp.out_twin = twin_out ? ws + net->tensors[to.twin].offset : nullptr;
@@ -2069,6 +2106,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     const Tensor& to = net->tensors[op.out];
                     UpsampleAddParams p;
                     memset(&p, 0, sizeof(p));
+                    p.range = net->d_range;
                     p.base = op.base >= 0 ? ws + net->tensors[op.base].offset : nullptr;
                     p.nsrc = op.nsrc;
                     int C0 = to.C;
@@ -2121,6 +2159,7 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                     const Tensor& to = net->tensors[op.out];
                     HeadParams hp;
                     memset(&hp, 0, sizeof(hp));
+                    hp.range = net->d_range;
                     hp.direct = ws + td.offset; hp.Cd = td.C;
                     hp.w0 = net->d_hw0; hp.bias0 = net->d_hb0; hp.w1 = net->d_hw1; hp.bias1 = net->d_hb1;
                     hp.w0_32 = net->d_hw0_32; hp.w1_32 = net->d_hw1_32; hp.ks16 = net->head_ks16;

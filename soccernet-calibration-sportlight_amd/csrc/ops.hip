@@ -27,16 +27,22 @@ template <> struct Vec<float> {
 
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N,
-                                                           int C, int H, int W) {
+                                                           int C, int H, int W, unsigned* __restrict__ nonfinite) {
     constexpr int GE = Vec<T>::GE;
+    bool bad = false;                                              // a NaN / infinite input value (the split engines' range flag, x3.hpp)
     const unsigned hw = (unsigned)(H * W);
     const size_t n = blockIdx.y;                                   // one image per grid row: no per-element division
     for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < hw; r += gridDim.x * 256u) {
         typename Vec<T>::type v;
 #pragma unroll
-        for (int c = 0; c < GE; ++c) v[c] = (T)(c < C ? x[(n * C + c) * hw + r] : 0.0f);
+        for (int c = 0; c < GE; ++c) {
+            const float f = c < C ? x[(n * C + c) * hw + r] : 0.0f;
+            bad = bad || !(__builtin_fabsf(f) <= 3.4028234663852886e38f);
+            v[c] = (T)f;
+        }
         *reinterpret_cast<typename Vec<T>::type*>(y + (n * hw + r) * GE) = v;
     }
+    if (nonfinite != nullptr && bad) atomicAdd(nonfinite, 1u);
 }
 
 // uint8 HWC frames (what cv2.imread hands to ToTensor, make_submit.py:62-66) -> NHWC T: ToTensor's float32 x / 255,
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
     const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, nj = gridDim.x >> 3;          // gridDim.x is a multiple of 8
     const unsigned row_lo = (unsigned)p.H * xcd / 8u, row_hi = (unsigned)p.H * (xcd + 1u) / 8u;
     const unsigned e_hi = row_hi * (unsigned)p.W * cg;
+    [[maybe_unused]] float amax = 0.f;                // fp32 path with a twin output: range tracker (x3.hpp)
     for (unsigned i = row_lo * (unsigned)p.W * cg + j * 256u + threadIdx.x; i < e_hi; i += nj * 256u) {
         const unsigned pl = udiv_magic(i, p.cg_shift, p.cg_magic);
         const int c0 = (int)(i - pl * cg) * GE;
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
 #pragma unroll
         for (int e = 0; e < GE; ++e) o[e] = (T)(p.relu ? fmaxf(acc[e], 0.f) : acc[e]);
         if constexpr (GE == 4) {
+            x3_track(amax, (float)o[0], (float)o[1]); x3_track(amax, (float)o[2], (float)o[3]);      // every output of the fp32 path (x3.hpp)
             if (p.out_twin) {          // bf16x3: hi = bf16(y), lo = bf16(y - hi) for the two-team convolution that reads this sum
                 x3h4 th, tl;
 #pragma unroll
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(UpsampleAddParams p) 
         }
         *reinterpret_cast<V*>(reinterpret_cast<T*>(p.out) + pix * p.out_cstride + p.out_coff + c0) = o;
     }
+    if constexpr (GE == 4) x3_report(amax, p.range);
 }
 
 // One workgroup = 64 consecutive pixels x up to 64 channels.  Reads are row-contiguous (4 lanes x 64 B per
@@ -197,12 +206,12 @@ static inline int grid_for(size_t items) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s) {
+int launch_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, hipStream_t s, unsigned* nonfinite) {
     const size_t total = (size_t)N * H * W;
     if (dtype == SNCAL_BF16)
-        SNCAL_LAUNCH(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W);
+        SNCAL_LAUNCH(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (__bf16*)y, N, C, H, W, nonfinite);
     else
-        SNCAL_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (float*)y, N, C, H, W);
+        SNCAL_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for((size_t)H * W), N), dim3(256), 0, s, x, (float*)y, N, C, H, W, nonfinite);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

@@ -50,24 +50,28 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16x8* __restr
 
 // fp32 [N][H][W][C] -> split twin for the split-arithmetic convolutions (conv_tt.hip MODE 2): per pixel and 16-channel group
 // [16 hi | 16 lo] 16-bit codes with hi = rne16(x), lo = rne16(x - hi) (x3.hpp).  One thread = 8 channels: 32 B read, 16 B + 16 B written.
-__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, x3h8* __restrict__ y, size_t n8) {
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4* __restrict__ x, x3h8* __restrict__ y, size_t n8, unsigned* __restrict__ range) {
+    float amax = 0.f;                                  // range tracker (x3.hpp)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         const float4 a = x[2 * i], b = x[2 * i + 1];
         const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         x3h8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) X3_SPLIT1(f[e], h[e], l[e]);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) x3_track(amax, f[e], f[e + 1]);
         const size_t g16 = i >> 1, half = i & 1;            // 16-channel group, which 8 of its channels
         y[g16 * 4 + half] = h;
         y[g16 * 4 + 2 + half] = l;
     }
+    x3_report(amax, range);
 }
 
-int launch_split_f32(const void* x, void* y, size_t n, hipStream_t s) {
+int launch_split_f32(const void* x, void* y, size_t n, hipStream_t s, unsigned* range) {
     if (n % 16) { set_error("split: element count %zu is not a multiple of 16", n); return SNCAL_ERR_ARG; }
     const size_t n8 = n / 8;
     const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 4096);
-    SNCAL_LAUNCH(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<x3h8*>(y), n8);
+    SNCAL_LAUNCH(split_f32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<x3h8*>(y), n8, range);
     SNCAL_CHECK_LAUNCH();
     return SNCAL_OK;
 }

@@ -115,6 +115,28 @@ __device__ __forceinline__ float x3_join(unsigned hi_pk, unsigned lo_pk) {
     return __uint_as_float(HALF ? lo_pk & 0xffff0000u : lo_pk << 16) + __uint_as_float(HALF ? hi_pk & 0xffff0000u : hi_pk << 16);
 #endif
 }
+// Run-time range flag (round 5).  The clamp above is silent by construction; a network whose activations really leave +-65504 -- the
+// reference's fp32 predict() has no such limit (src/models/hrnet/metamodel.py:127-134) -- must not come back with plausible heatmaps.
+// Every kernel that splits activations keeps the largest |value| it has split in one register (v_max3_f32 with |.| source modifiers:
+// half an instruction per value) and, when that exceeds the fp16 range, bumps a sticky per-network counter as it leaves
+// (sncal_hrnet_range_status).  |v| also counts a large NEGATIVE pre-activation that the ReLU would have zeroed anyway: a false alarm
+// in the safe direction.  Infinities count; a NaN cannot arise from finite weights (checked at finalize) and finite frames (checked by the
+// layout kernel) without an overflow first.  The bf16 build of the engine has fp32's exponent range: nothing to track.
+__device__ __forceinline__ void x3_track(float& amax, float a, float b) {
+#if SNCAL_X3_F16
+    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a)), __builtin_fabsf(b));
+#endif
+}
+__device__ __forceinline__ void x3_track1(float& amax, float a) {
+#if SNCAL_X3_F16
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
+#endif
+}
+__device__ __forceinline__ void x3_report(float amax, unsigned* range) {
+#if SNCAL_X3_F16
+    if (range != nullptr && amax > 65504.f) atomicAdd(range, 1u);
+#endif
+}
 typedef unsigned x3u4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x3_split8(const float (&v)[8], float lob, x3u4& hi, x3u4& lo) {
@@ -124,6 +146,17 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], float lob, x3u4& 
 __device__ __forceinline__ void x3_split4(const float (&v)[4], float lob, x3u2& hi, x3u2& lo) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) { unsigned h, l; x3_split2(v[2 * k], v[2 * k + 1], lob, h, l); hi[k] = h; lo[k] = l; }
+}
+
+// ... and the same with the range tracker (above) fed
+__device__ __forceinline__ void x3_split8(const float (&v)[8], float lob, x3u4& hi, x3u4& lo, float& amax) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x3_track(amax, v[2 * k], v[2 * k + 1]);
+    x3_split8(v, lob, hi, lo);
+}
+__device__ __forceinline__ void x3_split4(const float (&v)[4], float lob, x3u2& hi, x3u2& lo, float& amax) {
+    x3_track(amax, v[0], v[1]); x3_track(amax, v[2], v[3]);
+    x3_split4(v, lob, hi, lo);
 }
 
 // host side (weight packing): the same two codes

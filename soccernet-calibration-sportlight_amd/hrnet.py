@@ -147,7 +147,9 @@ class HRNetHeatmap:
         """Accepts the reference's nn_state_dict (keys 'model.conv1.weight', ... metamodel.py:108-124)."""
         sd = {k.replace('_orig_mod.', ''): v for k, v in state_dict.items()}
         used = set()
-        for i, (name, bn, cin, cout, k, stride, has_bias) in enumerate(self.conv_units()):
+        units = self.conv_units()
+        folded = []                                       # per unit: [weight fp64 (cout, cin, k, k), scale fp64, shift fp64]
+        for i, (name, bn, cin, cout, k, stride, has_bias) in enumerate(units):
             w = sd[name + '.weight'].detach().to('cpu', torch.float64)
             used.add(name + '.weight')
             if tuple(w.shape) != (cout, cin, k, k):
@@ -167,6 +169,9 @@ class HRNetHeatmap:
             else:
                 scale = torch.ones(cout, dtype=torch.float64)
                 shift = b
+            folded.append([w.clone(), scale, shift])
+        self.equalized = self._equalize_blocks(units, folded) if self.dtype_name == 'fp16x3' else 0
+        for i, (w, scale, shift) in enumerate(folded):
             wf = np.ascontiguousarray(w.to(torch.float32).numpy())
             sc = np.ascontiguousarray(scale.to(torch.float32).numpy())
             sh = np.ascontiguousarray(shift.to(torch.float32).numpy())
@@ -179,6 +184,45 @@ class HRNetHeatmap:
             _lib.check(self._L.sncal_hrnet_finalize(self._h), 'sncal_hrnet_finalize')
         self._loaded = True
         return self
+
+    @staticmethod
+    def _equalize_blocks(units, folded, min_log2: int = 4, centre: int = 2):
+        """Power-of-two rebalancing of block-internal channels for the split-fp16 engine (round 5).  fp16 halves carry 22 bits only for
+        |v| in [2^-3, 65504] and an ABSOLUTE 2^-25 below: a product w.x loses relative precision 2^-25 (1/|w| + 1/|x|), smallest when the
+        weight and the activation it meets are of one size.  A trained checkpoint need not be balanced -- a BatchNorm with a small gamma
+        in front of a convolution with large weights is the same function as the reverse -- and measured on a four-decade spread the engine
+        drifted to |dlogp| 5e-3 without any flag (tests/test_range_guard_gpu.py).  Inside a block the balance is free to choose, EXACTLY:
+        the output of conv1 + bn1 + ReLU of a BasicBlock (conv1 / conv2 of a Bottleneck) feeds one convolution only (hrnet.py:42-58, 79-99),
+        ReLU commutes with a positive factor, so row c of the producer (folded scale and shift) x 1/q_c and column c of the consumer x q_c,
+        q_c a power of two, is the same network bit for bit in fp32.  With m_c the size of the consumer column's large folded weights (90th percentile over its output channels) and
+        a_c = |shift_c| + |row c of the producer|_2 the size of the activation (unit-size inputs), l_c = round(log2(a_c / m_c) / 2) says how far
+        the two are apart; an ordinary checkpoint (Kaiming-size weights, unit-size activations) sits at l = `centre` = 2, the operating point
+        all goldens and parity workloads of the build were measured at.  Channels with |l_c - centre| >= min_log2 are brought back to it:
+        q_c = 2^(l_c - centre); everything else -- every channel of the build's own workloads -- is left untouched, bit for bit.
+        Tensors with several consumers (module outputs, the residual streams) are not rebalanced.  Returns the number of channels moved."""
+        moved = 0
+        for i in range(len(units) - 1):
+            name, bn, nxt = units[i][0], units[i][1], units[i + 1][0]
+            stem, leaf = name.rsplit('.', 1)
+            nstem, nleaf = nxt.rsplit('.', 1)
+            if not bn or stem != nstem or stem == 'model' or (leaf, nleaf) not in (('conv1', 'conv2'), ('conv2', 'conv3')):
+                continue
+            w1, sc1, sh1 = folded[i]
+            w2, sc2, _ = folded[i + 1]
+            m = (w2.abs() * sc2.abs().view(-1, 1, 1, 1)).amax(dim=(2, 3)).quantile(0.9, dim=0)   # consumer column c: its large folded weights
+            #   (90th percentile over the output channels of the largest tap, not the maximum: ONE outlier row -- a near-dead BatchNorm behind the consumer -- must not
+            #   drag every column down with it; that row is for sncal_hrnet_finalize's range check to refuse)
+            a = sh1.abs() + torch.sqrt((w1 * sc1.view(-1, 1, 1, 1)).pow(2).sum(dim=(1, 2, 3)))     # producer row c: size of its output
+            ok = (m > 0) & (a > 0) & torch.isfinite(m) & torch.isfinite(a)
+            lg = torch.where(ok, torch.round(0.5 * torch.log2(torch.where(ok, a / torch.where(ok, m, torch.ones_like(m)), torch.ones_like(a)))), torch.zeros_like(a))
+            lg = lg - centre                                   # distance from the balance of an ordinary checkpoint
+            lg = torch.where(lg.abs() >= min_log2, lg, torch.zeros_like(lg)).clamp(-60, 60)
+            q = torch.exp2(lg)
+            folded[i][1] = sc1 / q
+            folded[i][2] = sh1 / q
+            folded[i + 1][0] = w2 * q.view(1, -1, 1, 1)
+            moved += int((lg != 0).sum())
+        return moved
 
     # ---- forward --------------------------------------------------------------------------------
     def output_size(self, H, W):
@@ -223,6 +267,18 @@ class HRNetHeatmap:
                           ws.data_ptr(), ws.numel(), _lib.current_stream_ptr()),
                        'sncal_hrnet_forward')
         return heat, kpts
+
+    def range_status(self, clear: bool = True, check: bool = False):
+        """(overflow, nonfinite) since the last clear: wavefronts of the split-fp16 engine that clamped an activation beyond +-65504, and
+        workgroups that met a NaN / infinite input value (sncal_hrnet_range_status; synchronises the current stream).  The reference's
+        predict() is fp32 and has no such limit (metamodel.py:127-134): a non-zero count means the forwards since the last clear are NOT
+        its result.  check=True raises SncalRangeError instead of returning the counts.  Always (0, 0) on the other engines."""
+        ov, nf = ctypes.c_uint(), ctypes.c_uint()
+        with torch.cuda.device(self.device):
+            st = self._L.sncal_hrnet_range_status(self._h, ctypes.byref(ov), ctypes.byref(nf), int(bool(clear)), _lib.current_stream_ptr())
+        if st != 0 and (check or st != _lib.ERR_RANGE):
+            _lib.check(st, 'sncal_hrnet_range_status')
+        return ov.value, nf.value
 
     # ---- C5: fp8 arithmetic in the wide 3x3 convolutions (dtype='fp8') -------------------------------------------
     def calibrate_fp8(self, x: torch.Tensor):

@@ -37,10 +37,17 @@ class HRNetMetaModel:
         if self.prediction_transform is None:
             raise _lib.SncalError('predict(): params hold no prediction_transform')
         x = x.to(self.device, non_blocking=True)
+        self.check_range()              # the range flag of the PREVIOUS calls (their results have been consumed by now: no stall)
         pt = self.prediction_transform
         if isinstance(pt, HRNetPredictionTransform):     # fused: decode straight from the engine
             return self.nn_module.forward(x, want_heat=False, decode_size=(pt.H, pt.W))[1]
         return pt(self.nn_module(x)[-1])
+
+    def check_range(self):
+        """Raise SncalRangeError if a forward since the last check left the split-fp16 engine's range (HRNetHeatmap.range_status):
+        its output was NOT the reference's fp32 result.  predict() checks the calls before it; call this after the last one."""
+        if self.nn_module.dtype_name == 'fp16x3':
+            self.nn_module.range_status(clear=True, check=True)
 
     def eval(self):
         return self

@@ -108,13 +108,15 @@ class CalibrationPipeline:
         pool[1] = (k + 1) % len(streams)
         return streams[k]
 
-    def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False):
+    def submit(self, frames: torch.Tensor, names=None, extra_keypoints: torch.Tensor = None, gather: bool = False,
+               solve_decoded: bool = True):
         """frames (B,3,H,W) fp32 (ToTensor's output) or (B,H,W,3) uint8 BGR (cv2.imread's / JpegDecoder.decode's
         output) on the GPU.  Enqueues forward+decode on the current stream and the solve(s) on a solve stream; returns
         (kpts, records[, extra_records][, all_ranks_records]) device tensors (asynchronous; `join()` / `cameras()` /
         `last_done` order a consumer behind them).  gather=True (multi-GPU): the one collective of the path --
         every rank's per-frame records to every rank -- is enqueued on the solve stream behind the solves, so the next
-        batch's convolutions never wait for it."""
+        batch's convolutions never wait for it.  solve_decoded=False (measurement aid, tools/noisy_pipeline.py): the step's ONE
+        solve is that of `extra_keypoints`; the records slot of the decoded keypoints is returned as None."""
         main = torch.cuda.current_stream(self.device)
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
         if self.line_net is not None:
@@ -139,7 +141,7 @@ class CalibrationPipeline:
             kpts.record_stream(side)
             if d_lp is not None:
                 d_lp.record_stream(side)
-            rec = self.calibrator.solve_device(kpts, d_lp)
+            rec = self.calibrator.solve_device(kpts, d_lp) if solve_decoded or extra_keypoints is None else None
             out = [kpts, rec]
             if extra_keypoints is not None:
                 extra_keypoints.record_stream(side)
@@ -162,10 +164,18 @@ class CalibrationPipeline:
             cur.wait_event(ev)
         self._pending.clear()
 
+    def check_range(self):
+        """Raise SncalRangeError if a forward since the last check left the split-fp16 engine's range (HRNetHeatmap.range_status):
+        keypoints and cameras of those batches are not the reference's fp32 results.  Synchronises the current stream."""
+        for n in (self.net, self.line_net):
+            if n is not None and n.dtype_name == 'fp16x3':
+                n.range_status(clear=True, check=True)
+
     def cameras(self, records: torch.Tensor):
         """records from submit() -> list of Optional[Camera] (synchronises)."""
         from .prediction import camera_from_record
         for ev in self._pending:
             ev.synchronize()
         self._pending.clear()
+        self.check_range()
         return [camera_from_record(r, self.calibrator.img_size) for r in self.calibrator.records(records)]

@@ -133,6 +133,7 @@ def _make_submit(img_dir: str, model, calibrator: CameraCreator, save_dir: str, 
         drain(1)                                                                    # write batch k-1 while batch k runs
     drain(0)
     pipe.join()
+    pipe.check_range()                                                              # the split-fp16 engine's range flag: raises if any batch left the fp16 range
     dec.close()
     if len(skipped) > max_skip_fraction * total:
         raise _lib.SncalError(f'{len(skipped)} of {total} frames were skipped (first: {skipped[0]}): more than the allowed fraction '

@@ -304,6 +304,41 @@ def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: f
 
 
 # ---- synthetic annotations (N4 geometry tests): the pitch's lines and circles as a SoccerNet annotator would click them ----
+def rescaled_state_dict(sd: dict, conv_units, seed: int = 0, sigma_log2: float = 3.0, dead_frac: float = 0.01, dead_log2: int = -12,
+                         max_log2: int = 10, only=None, k_fixed=None) -> dict:
+    """A "trained-like" spread of scales WITHOUT changing the function: for every block-internal BatchNorm (bn1 of a BasicBlock, bn1 and bn2
+    of a Bottleneck -- its output feeds exactly one convolution) channel c gets s_c = 2^k_c: gamma_c, beta_c *= s_c and column c of the
+    next convolution's weight /= s_c.  ReLU commutes with a positive scale and powers of two are exact, so the fp32 network's output is
+    BIT-identical (hrnet.py:42-58, 79-99), while the internal activations and the folded weights now span decades the way a trained
+    checkpoint's do: k_c ~ round(N(0, sigma_log2)) clipped to [-max_log2, max_log2] (sigma 3 -> about four decades), and a fraction
+    `dead_frac` of near-dead channels at 2^dead_log2.  `conv_units` = HRNetHeatmap.conv_units(); `only` = substring filter on the
+    first convolution's name; `k_fixed` = the same exponent for every channel (the scale-equivariance test).  Workload / test generator."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {k: v.clone() for k, v in sd.items()}
+    units = list(conv_units)
+    for i in range(len(units) - 1):
+        name, bn, cin, cout = units[i][0], units[i][1], units[i][2], units[i][3]
+        nxt = units[i + 1][0]
+        stem, leaf = name.rsplit('.', 1)
+        nstem, nleaf = nxt.rsplit('.', 1)
+        if not bn or stem != nstem or stem == 'model' or (leaf, nleaf) not in (('conv1', 'conv2'), ('conv2', 'conv3')):      # (the stem's bn1 also feeds the head)
+            continue
+        if only is not None and only not in name:
+            continue
+        if k_fixed is not None:
+            k = np.full(cout, int(k_fixed))
+        else:
+            k = np.clip(np.rint(rng.normal(0.0, sigma_log2, cout)), -max_log2, max_log2).astype(np.int64)
+            k[rng.random(cout) < dead_frac] = dead_log2
+        s_c = torch.from_numpy(np.exp2(k.astype(np.float64))).to(out[bn + '.weight'].dtype)
+        out[bn + '.weight'] = out[bn + '.weight'] * s_c
+        out[bn + '.bias'] = out[bn + '.bias'] * s_c
+        w = out[nxt + '.weight']
+        out[nxt + '.weight'] = w / s_c.to(w.dtype).view(1, -1, 1, 1)
+    return out
+
+
 def synthetic_annotation(seed: int = 0, pts_per_line: int = 6, noise_px: float = 0.3):
     """{annotation class: [(x, y) normalised to the 960x540 image]} for one sampled camera: every pitch line that runs through
     at least two template intersections (sampled between its extreme intersection points) and the three circles, projected,

@@ -13,12 +13,24 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 row_gain = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 dev = torch.device('cuda:0')
 sd = sncal_amd.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True, row_gain=row_gain)
+# PARITY_TRAINED_LIKE=<seed>: the same function with a trained checkpoint's spread of scales -- every block-internal channel x 2^k, k ~ N(0, 3)
+# (four decades), 2 % near-dead channels at 2^-12, the next convolution's column x 2^-k (synth.rescaled_state_dict: bit-identical in fp32).
+# PARITY_NO_EQUALIZE=1 switches the load-time rebalancing of the fp16x3 engine off (HRNetHeatmap._equalize_blocks): what it is there for.
+trained_like = os.environ.get('PARITY_TRAINED_LIKE')
+if trained_like is not None:
+    units = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='fp32', device='cpu').conv_units()
+    sd = sncal_amd.synth.rescaled_state_dict(sd, units, seed=int(trained_like), sigma_log2=3.0, dead_frac=0.02)
+if os.environ.get('PARITY_NO_EQUALIZE') == '1':
+    sncal_amd.HRNetHeatmap._equalize_blocks = staticmethod(lambda units, folded, **kw: 0)
 cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **bench.SOLVER_KW)
 res = {}
 kps = {}
 for dtype in ('fp32', 'fp16x3', 'bf16'):
     net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
-    net.load_state_dict(sd)
+    try:
+        net.load_state_dict(sd)
+    except sncal_amd._lib.SncalRangeError as e:
+        print(dtype, 'REFUSED:', str(e)[:200]); res[dtype] = {'refused': str(e)}; continue
     out = []
     for lo in range(0, N, 64):
         n = min(64, N - lo)
@@ -26,9 +38,14 @@ for dtype in ('fp32', 'fp16x3', 'bf16'):
         _, kp = net.forward(torch.from_numpy(frames).to(dev), want_heat=False, decode_size=(540, 960))
         out.append(kp.clone())
     kps[dtype] = torch.cat(out, 0)
+    if dtype == 'fp16x3':
+        res['fp16x3_range_status'] = list(net.range_status()); res['fp16x3_channels_rebalanced'] = int(getattr(net, 'equalized', 0))
+        print('fp16x3 range status', res['fp16x3_range_status'], 'channels rebalanced at load', res['fp16x3_channels_rebalanced'])
     del net
 recs = {d: cc.records(cc.solve_device(kps[d])) for d in kps}
 for d in ('fp16x3', 'bf16'):
+    if d not in kps:
+        continue
     res[d] = bench.parity_of(kps['fp32'].cpu().numpy(), recs['fp32'], kps[d].cpu().numpy(), recs[d], 'exact-fp32 engine of this build')
     res[d]['row_gain'] = row_gain
     print(d, {k: res[d][k] for k in ('frames', 'usable_keypoints', 'moved_usable_keypoints', 'index_agreement', 'index_agreement_all_rows', 'cameras_both',
@@ -74,5 +91,6 @@ for i in range(N):
 res['fp16x3']['cameras_differ_without_moved_usable_index'] = odd
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 res['split_type'] = sncal_amd._lib.lib().sncal_x3_name().decode()
-tag = os.environ.get('PARITY_TAG', res['split_type'])
+res['trained_like_seed'] = trained_like
+tag = os.environ.get('PARITY_TAG', res['split_type'] + ('' if trained_like is None else f'_trainedlike{trained_like}') + ('_noeq' if os.environ.get('PARITY_NO_EQUALIZE') == '1' else ''))
 json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'parity_large_{N}_rowgain{row_gain}_{tag}.json'), 'w'), indent=1)

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+timeout 900 python -m pytest tests/test_range_guard_gpu.py -m gpu -q -k finalize 2>&1 | grep -B5 -A12 "^E " | head -60

@@ -293,6 +293,46 @@ def lanes_leg(sncal_amd, cfg_name, sd, x, cc, dev, dtype, lanes=2, steps=5, warm
                     'not the driver line: per-kernel durations of a shared GPU do not make a roofline'}
 
 
+def input_stage_leg(sncal_amd, net, cc, dev, steps=6, B=BATCH):
+    """N3 (make_submit.py:56-67: cv2.imread + ToTensor on the host): frames/s of the JPEG input stage on this box -- JpegDecoder.decode
+    alone (Huffman decode on `threads` host threads, dequantise + IDCT + colour conversion on the GPU) and the whole pipeline fed from JPEG
+    bytes (the host decodes batch k + 1 while the GPU runs batch k).  The frame is the 960x540 4:2:0 test frame of tests/golden
+    (libjpeg-turbo byte-equal); its pixels mean nothing to the network, so the solve finds no cameras: an input-stage figure, outside the
+    timed region, not a second bench line."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'jpeg_cases.npz'))
+    blob = g['jpg.full'].tobytes()
+    cores, why = usable_cores()
+    threads = max(1, min(cores, 32))
+    dec = sncal_amd.JpegDecoder(540, 960, max_batch=B, threads=threads, device=dev)
+    bufs = [torch.empty((B, 540, 960, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    blobs = [blob] * B
+    for k in range(2):
+        dec.decode(blobs, bufs[k])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        dec.decode(blobs, bufs[k & 1])
+    torch.cuda.synchronize()
+    t_dec = (time.perf_counter() - t0) / steps
+    pipe = sncal_amd.CalibrationPipeline(net, cc, decode_size=(540, 960))
+    for k in range(2):
+        pipe.submit(dec.decode(blobs, bufs[k & 1]))
+    pipe.join()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pipe.submit(dec.decode(blobs, bufs[k & 1]))
+    pipe.join()
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t0) / steps
+    dec.close()
+    return {'jpeg_bytes_per_frame': len(blob), 'frame': '960x540 4:2:0 baseline JPEG (tests/golden/jpeg_cases.npz jpg.full)', 'host_threads': threads, 'cores': why,
+            'decode_alone_frames_per_s': round(B / t_dec, 1), 'decode_alone_ms_per_batch': round(t_dec * 1e3, 2),
+            'pipeline_from_jpeg_frames_per_s': round(B / t_pipe, 1), 'pipeline_from_jpeg_ms_per_step': round(t_pipe * 1e3, 2), 'steps': steps,
+            'what': 'JpegDecoder.decode alone, and decode + forward + decode + solve with the host Huffman stage of batch k + 1 beside the GPU work of batch k '
+                    '(Huffman on the host threads this process may use; the rest on the GPU)'}
+
+
 def parity_of(kp32, r32, kpf, rf, versus):
     """Keypoints / cameras of one engine against the exact-fp32 engine's on the same frames (all frames with two cameras)."""
     same = (kp32[..., :2] == kpf[..., :2]).all(-1)                       # (B,57) identical (x, y) indices
@@ -685,6 +725,11 @@ def main():
             out[other] = out_other
             if args.size == '540p' and not c4 and L == 1 and args.dtype != 'fp8':
                 out['lanes2'] = lanes_leg(sncal_amd, cfg_name, sd, x, cc, dev, args.dtype)
+        if world == 1 and not args.no_parity and args.size == '540p' and not c4 and args.dtype != 'fp8':
+            try:
+                out['input_stage'] = input_stage_leg(sncal_amd, nets[0], cc, dev)
+            except Exception as e:                                   # (a box without the golden file: the line stays valid)
+                out['input_stage'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, cfg_name, frames_cpu, kpf, nb=8 if args.size == '540p' else 2)
         print(json.dumps(out), flush=True)

@@ -18,7 +18,7 @@ import torch
 from oracle import hrnet_ref as hr
 
 pytestmark = pytest.mark.gpu
-TOL_LOGP = 2.5e-4          # the fp16x3 engine's golden tolerance on log-probabilities (tests/test_hrnet_gpu.py)
+TOL_LOGP = 2e-4            # the golden tolerance on log-probabilities, fp32 and fp16x3 engines alike (tests/test_hrnet_gpu.py)
 
 
 def _nets(sncal, cuda, sd, dtype):

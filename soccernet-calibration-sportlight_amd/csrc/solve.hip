@@ -61,6 +61,33 @@ __device__ __forceinline__ double wmax(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Reductions over aligned groups of W lanes (W = 8, 16, 32, 64) for the packed LM below: every lane ends with the sum / maximum of ITS
+// group, and all groups of a wave hold the same points there, so every lane ends with the same bits.  Written with DPP moves -- quad
+// swaps, row_half_mirror, row_mirror: three instructions per step and 64-bit value, no LDS round trip -- and, across the four rows of 16,
+// v_readlane of the row leaders; as __shfl_xor in a non-inlined device function the same butterflies came out as ds_bpermute pairs
+// (708 per iteration at W = 64 where the inlined round-4 code had 352 DPP moves: 2.6 -> 7.0 us per iteration on a 31-point fit, measured).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value64(double v, int lane) {      // wave-uniform copy of lane `lane`'s value
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <int W, bool MAX>
+__device__ __forceinline__ double wred_w(double v) {
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
+    v = op(v, dpp_mov64<0xB1>(v));                    // quad_perm [1,0,3,2]: lane ^ 1
+    v = op(v, dpp_mov64<0x4E>(v));                    // quad_perm [2,3,0,1]: lane ^ 2
+    v = op(v, dpp_mov64<0x141>(v));                   // row_half_mirror: the other quad of the 8
+    if constexpr (W >= 16) v = op(v, dpp_mov64<0x140>(v));       // row_mirror: the other half of the row of 16
+    if constexpr (W == 32) v = op(lane_value64(v, 0), lane_value64(v, 16));          // (both groups hold the same points: group 0's total)
+    if constexpr (W == 64) v = op(op(lane_value64(v, 0), lane_value64(v, 16)), op(lane_value64(v, 32), lane_value64(v, 48)));
+    return v;
+}
+template <int W> __device__ __forceinline__ double wsum_w(double v) { return wred_w<W, false>(v); }
+template <int W> __device__ __forceinline__ double wmax_w(double v) { return wred_w<W, true>(v); }
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
 __device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
 __device__ __forceinline__ int kth_set_bit(u64 m, int k) {
@@ -677,6 +704,7 @@ __device__ void sym_solve6(const double (&A)[6][6], const double (&b)[6], double
 }
 
 // normal equations of the pose problem at x = [rvec, tvec]: A = J^T J, g = J^T r, S = |r|^2, rinf = |r|_inf (all wave-uniform)
+template <int W = 64>
 __device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const double* X, double u, double v, bool want_j,
                                double (&A)[6][6], double (&g)[6], double& S, double& rinf) {
     const int lane = threadIdx.x & 63;
@@ -691,10 +719,10 @@ __device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const dou
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
             for (int j = i; j < 6; ++j) {
-                const double s = wsum(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
+                const double s = wsum_w<W>(in ? ju[i] * ju[j] + jv[i] * jv[j] : 0.0);
                 A[i][j] = s; A[j][i] = s;
             }
-            g[i] = wsum(in ? ju[i] * ru + jv[i] * rv : 0.0);
+            g[i] = wsum_w<W>(in ? ju[i] * ru + jv[i] * rv : 0.0);
         }
     } else {
         double Xc[3];
@@ -702,18 +730,97 @@ __device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const dou
         const double z = fabs(Xc[2]) < 1e-12 ? 1e-12 : Xc[2];
         ru = k.fx * Xc[0] / z + k.cx - u; rv = k.fy * Xc[1] / z + k.cy - v;
     }
-    S = wsum(in ? ru * ru + rv * rv : 0.0);
-    rinf = wmax(in ? fmax(fabs(ru), fabs(rv)) : 0.0);
+    S = wsum_w<W>(in ? ru * ru + rv * rv : 0.0);
+    rinf = wmax_w<W>(in ? fmax(fabs(ru), fabs(rv)) : 0.0);
+}
+
+// Cholesky of a 6 x 6 system for the LM below, with the diagonal kept as RECIPROCALS: L[i][j] = s * rinv[j] and the substitutions
+// multiply -- 6 reciprocal square roots per factorisation and no division in a solve, where chol_solve's form has 6 square roots + 15
+// divisions per factorisation and 12 dependent divisions per solve.  refine_camera's slow fits (20000 iterations at the reference's
+// criterion, camera.py:116) are ONE wavefront issuing ~2200 dependent fp64 instructions per iteration: 7.8 us each, 160 ms for the fit that
+// sets the latency of a batch's solve; a fifth of those instructions were divisions.  Same pivot rule as sym_factor6 (a
+// failing pivot sends the caller to its eigen-decomposition fallback); results differ from the dividing form by rounding only.
+struct Chol6 { double L[6][6]; double rinv[6]; bool ok; };
+__device__ __forceinline__ void chol6_factor(const double (&A)[6][6], Chol6& F) {
+    double dmax = A[0][0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) dmax = fmax(dmax, A[i][i]);
+    bool ok = dmax > 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= F.L[j][k] * F.L[j][k];
+        if (!(d > 1e-11 * dmax)) { ok = false; d = 1.0; }
+        const double ri = rsqrt(d);
+        F.rinv[j] = ri;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double sacc = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc -= F.L[i][k] * F.L[j][k];
+            F.L[i][j] = sacc * ri;
+        }
+    }
+    F.ok = ok;
+}
+__device__ __forceinline__ void chol6_apply(const Chol6& F, const double (&b)[6], double (&x)[6]) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sacc = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= F.L[i][k] * y[k];
+        y[i] = sacc * F.rinv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sacc = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) sacc -= F.L[k][i] * x[k];
+        x[i] = sacc * F.rinv[i];
+    }
+}
+// max_e |(A^-1)_ee| from the factor: A^-1 = L^-T L^-1, so (A^-1)_ee = sum_i (L^-1)_ie^2 -- column e of L^-1 by one forward
+// substitution of a unit vector, instead of six full solves
+__device__ __forceinline__ double chol6_inv_diag_max(const Chol6& F) {
+    double mx = 0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        double z[6], acc = 0;
+#pragma unroll
+        for (int i = e; i < 6; ++i) {
+            double sacc = i == e ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = e; k < i; ++k) sacc -= F.L[i][k] * z[k];
+            z[i] = sacc * F.rinv[i];
+            acc += z[i] * z[i];
+        }
+        mx = fmax(mx, acc);
+    }
+    return mx;
 }
 
 // cv.solvePnPRefineLM = LMSolver::run (calib3d levmarq.cpp): D = diag(J^T J) fixed at the start, lambda_0 = 1, gain-ratio schedule
-// (0.25 / 0.75, nu in [2, 10], lambda -> 0 below lambda_c), accept when the error falls, stop on |d|_inf < eps or |r|_inf < eps
-__device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v, int max_iters, double eps) {
+// (0.25 / 0.75, nu in [2, 10], lambda -> 0 below lambda_c), accept when the error falls, stop on |d|_inf < eps or |r|_inf < eps.
+// W: the points sit in every aligned group of W lanes (cam_refine packs them when there are few: a reduction is then log2 W butterfly
+// steps instead of six); W = 64 is the plain one-point-per-lane layout.
+// (One copy of the loop per W in a kernel, not one per call site: a real function -- with every operand passed BY VALUE, in registers;
+// through pointers the pose and the lane's point would live in scratch memory and every iteration would fetch them from there: measured,
+// 2.6 -> 7.0 us per iteration on a 31-point fit.)
+struct LmPose { double R[9], t[3]; };
+template <int W>
+__device__ __attribute__((noinline)) LmPose lm_solver_pose_fn(u64 mask, LmPose io, K4 k, double X0, double X1, double X2, double u, double v, int max_iters, double eps) {
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = io.R[i];
+    t[0] = io.t[0]; t[1] = io.t[1]; t[2] = io.t[2];
+    const double X[3] = {X0, X1, X2};
     double x[6];
     log_so3(R, x);
     x[3] = t[0]; x[4] = t[1]; x[5] = t[2];
     double A[6][6], g[6], S, rinf;
-    pose_normal_eq(mask, x, k, X, u, v, true, A, g, S, rinf);
+    pose_normal_eq<W>(mask, x, k, X, u, v, true, A, g, S, rinf);
     double D[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) D[i] = A[i][i];
@@ -724,11 +831,16 @@ __device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, cons
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) Ap[i][j] = A[i][j] + (i == j ? lam * D[i] : 0.0);
-        sym_solve6(Ap, g, d);
+        {
+            Chol6 F;
+            chol6_factor(Ap, F);
+            if (F.ok) chol6_apply(F, g, d);
+            else sym_solve6(Ap, g, d);                // not positive definite: the eigen-decomposition fallback (cv::solve DECOMP_EIG)
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) xd[i] = x[i] - d[i];
         double A2[6][6], g2[6], Sd, rinf_d;
-        pose_normal_eq(mask, xd, k, X, u, v, false, A2, g2, Sd, rinf_d);
+        pose_normal_eq<W>(mask, xd, k, X, u, v, false, A2, g2, Sd, rinf_d);
         double dS = 0, dv_ = 0, dmax = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -748,14 +860,20 @@ __device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, cons
             nu = fmin(fmax(nu, 2.0), 10.0);
             if (lam == 0.0) {
                 double mx = DBL_EPS;
-                Sym6 F;                              // one factorisation for the six columns of the inverse
-                sym_factor6(A, F);
+                Chol6 C;
+                chol6_factor(A, C);
+                if (C.ok) {
+                    mx = fmax(mx, chol6_inv_diag_max(C));
+                } else {
+                    Sym6 F;                          // one factorisation for the six columns of the inverse
+                    sym_factor6(A, F);
 #pragma unroll
-                for (int e = 0; e < 6; ++e) {
-                    double unit[6] = {0, 0, 0, 0, 0, 0}, col[6];
-                    unit[e] = 1.0;
-                    sym_apply6(F, unit, col);
-                    mx = fmax(mx, fabs(col[e]));
+                    for (int e = 0; e < 6; ++e) {
+                        double unit[6] = {0, 0, 0, 0, 0, 0}, col[6];
+                        unit[e] = 1.0;
+                        sym_apply6(F, unit, col);
+                        mx = fmax(mx, fabs(col[e]));
+                    }
                 }
                 lam = lc = 1.0 / mx;
                 nu *= 0.5;
@@ -765,13 +883,55 @@ __device__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, cons
         if (Sd < S) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) x[i] = xd[i];
-            pose_normal_eq(mask, x, k, X, u, v, true, A, g, S, rinf);
+            pose_normal_eq<W>(mask, x, k, X, u, v, true, A, g, S, rinf);
         }
         ++it;
         if (!(it < max_iters && dmax >= eps && rinf >= eps)) break;
     }
     exp_so3(x, R);
-    t[0] = x[3]; t[1] = x[4]; t[2] = x[5];
+    LmPose out;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.R[i] = R[i];
+    out.t[0] = x[3]; out.t[1] = x[4]; out.t[2] = x[5];
+    return out;
+}
+template <int W = 64>
+__device__ __forceinline__ void lm_solver_pose(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v, int max_iters, double eps) {
+    LmPose io;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) io.R[i] = R[i];
+    io.t[0] = t[0]; io.t[1] = t[1]; io.t[2] = t[2];
+    const LmPose o = lm_solver_pose_fn<W>(mask, io, k, X[0], X[1], X[2], u, v, max_iters, eps);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = o.R[i];
+    t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+}
+
+// lm_solver_pose with the points PACKED when there are few: point r (the r-th set bit of `mask`) goes to lane g * W + r of every aligned
+// group g of W = 8 / 16 / 32 lanes, so that the 31 reductions of an iteration are 3 / 4 / 5 butterfly steps instead of 6 and every lane still
+// ends with the same sums (all groups hold the same points).  The slow fits are the ill-posed ones, and those have few points (the
+// bench's frame 16: 8).  More than 32 points: the plain layout.  The summation order depends on W, the results on nothing else.
+template <int W>
+__device__ __forceinline__ void lm_solver_pose_packed(u64 mask, int n, double* R, double* t, const K4& k, const double* X, double u, double v,
+                                                      int max_iters, double eps) {
+    const int lane = threadIdx.x & 63, r = lane & (W - 1);
+    u64 m = mask;
+    for (int i = 0; i < r; ++i) m &= m - 1;                      // (per-lane trip count, once per fit)
+    const int src = (r < n && m) ? __ffsll((long long)m) - 1 : lane;
+    const double Xp[3] = {__shfl(X[0], src, 64), __shfl(X[1], src, 64), __shfl(X[2], src, 64)};
+    const double up = __shfl(u, src, 64), vp = __shfl(v, src, 64);
+    const u64 grp = n >= 64 ? ~0ull : ((1ull << n) - 1);
+    u64 pm = 0;
+#pragma unroll
+    for (int g = 0; g < 64 / W; ++g) pm |= grp << (g * W);
+    lm_solver_pose<W>(pm, R, t, k, Xp, up, vp, max_iters, eps);
+}
+__device__ void lm_solver_pose_auto(u64 mask, double* R, double* t, const K4& k, const double* X, double u, double v, int max_iters, double eps) {
+    const int n = popc64(mask);
+    if (n >= 1 && n <= 8) lm_solver_pose_packed<8>(mask, n, R, t, k, X, u, v, max_iters, eps);
+    else if (n <= 16 && n >= 1) lm_solver_pose_packed<16>(mask, n, R, t, k, X, u, v, max_iters, eps);
+    else if (n <= 32 && n >= 1) lm_solver_pose_packed<32>(mask, n, R, t, k, X, u, v, max_iters, eps);
+    else lm_solver_pose<64>(mask, R, t, k, X, u, v, max_iters, eps);
 }
 
 // cvFindExtrinsicCameraParams2's refinement (solvePnPRansac's final SOLVEPNP_ITERATIVE refit, calibrateCamera's per-view initial
@@ -1195,7 +1355,7 @@ __device__ void cam_refine(Cam& c, u64 mask, const Pts& p) {
     for (int i = 0; i < 9; ++i) R[i] = c.R[i];
     cam_t(c, t);
     const K4 k{c.fx, c.fy, c.cx, c.cy};
-    if (p.sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, p.X64, p.u, p.v, p.refine_iters, 1e-5);      // camera.py:116-117
+    if (p.sched == SCHED_OPENCV) lm_solver_pose_auto(mask, R, t, k, p.X64, p.u, p.v, p.refine_iters, 1e-5);      // camera.py:116-117
     else refine_pose_lm(mask, R, t, k, p.X64, p.u, p.v, 100, 1e-10);
     cam_set_pose(c, R, t);
 }
@@ -1767,7 +1927,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const double* __restrict__ Kin,
     bool ok = true;
     if (mode == 0) {
         for (int i = 0; i < 3; ++i) t[i] = -(R[i * 3] * pos[0] + R[i * 3 + 1] * pos[1] + R[i * 3 + 2] * pos[2]);
-        if (sched == SCHED_OPENCV) lm_solver_pose(mask, R, t, k, X, u, v, max_iters, eps);
+        if (sched == SCHED_OPENCV) lm_solver_pose_auto(mask, R, t, k, X, u, v, max_iters, eps);
         else refine_pose_lm(mask, R, t, k, X, u, v, max_iters, eps);
     } else {
         // plane membership for the minimal solver = points with z == 0 (ids outside top_gates)

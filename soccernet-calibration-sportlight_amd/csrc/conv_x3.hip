@@ -8,6 +8,14 @@ static const ConvVariant k_variants_x3[] = {
 #include "conv_variants.inc"
 #undef V
 };
+void launch_conv_shared_s2_x3(const ConvSharedParams& sp, unsigned blocks, size_t lds, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_shared_s2_kernel<x3_t, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    SNCAL_LAUNCH((conv_shared_s2_kernel<x3_t, 2, 3>), dim3(blocks), dim3(256), lds, s, sp);
+}
 const ConvVariant* conv_variants_x3(int* n) {
     *n = (int)(sizeof(k_variants_x3) / sizeof(k_variants_x3[0]));
     return k_variants_x3;

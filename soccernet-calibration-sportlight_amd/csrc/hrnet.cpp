@@ -80,6 +80,7 @@ struct Op {
     int dims_from = -1, dims_mul = 1;     // UPADD without base: out dims = dims(dims_from) * dims_mul
     int group = GRP_ALL;
     int launch_group = -1;                // >= 0: independent convs that may share one grouped launch (consecutive ops)
+    bool shared_in = false;               // ... and all members read the SAME input tensor with stride 2 (conv_shared_s2_kernel)
     int head_direct = -1, head_src[HEAD_MAX_SRC] = {-1, -1, -1, -1, -1}, head_nsrc = 0;   // OP_HEAD
     int head_fold[HEAD_MAX_FOLD] = {-1, -1}, head_nfold = 0;                              // OP_HEAD: branches folded into stage-1 K
 };
@@ -317,6 +318,67 @@ struct Builder {
         return conv(p + ".conv3", t, true, res);
     }
 
+    // The ops of one module's fuse section, re-ordered (the reference registers them output by output, hrnet.py:229-244): the stride-2
+    // convolutions that START a fuse-down chain on the same input tensor become one launch group of consecutive ops, so that the executor
+    // can run them as ONE launch that fetches the input once (conv.hpp conv_shared_s2_kernel).  A list scheduler over the section's own data
+    // dependences: ops go out in the reference's order as they become ready; a group goes out as a whole, when its last member is ready
+    // (members never depend on each other: a chain's first convolution reads a module input, and its accumulate operand comes from chains
+    // of OTHER inputs).  Sums are accumulated in the reference's order: same bits.  SNCAL_SHARE_S2=0 keeps the reference's op order.
+    void schedule_fuse_section(size_t begin) {
+        static const bool off = getenv("SNCAL_SHARE_S2") && atoi(getenv("SNCAL_SHARE_S2")) == 0;
+        const size_t n = net.ops.size() - begin;
+        if (off || n < 3) return;
+        std::vector<Op> sec(net.ops.begin() + begin, net.ops.end());
+        std::map<int, int> producer;                         // tensor -> op of the section that writes it
+        for (size_t i = 0; i < n; ++i) if (sec[i].out >= 0) producer[sec[i].out] = (int)i;
+        auto reads = [&](const Op& o) {
+            std::vector<int> r{o.in, o.res, o.base, o.dims_from};
+            for (int k = 0; k < o.nsrc; ++k) r.push_back(o.srcs[k]);
+            return r;
+        };
+        std::vector<int> grp(n, -1);                          // group key per op: existing launch groups keep theirs
+        std::map<int, std::vector<int>> shared;               // input tensor -> chain-starting stride-2 convolutions
+        for (size_t i = 0; i < n; ++i) {
+            const Op& o = sec[i];
+            if (o.launch_group >= 0) { grp[i] = o.launch_group; continue; }
+            if (o.type == OP_CONV && net.layers[o.conv].stride == 2 && net.layers[o.conv].k == 3 && !producer.count(o.in)) shared[o.in].push_back((int)i);
+        }
+        for (auto& kv : shared) {
+            if (kv.second.size() < 2) continue;
+            for (size_t k = 0; k < kv.second.size(); k += 3) {      // launches take up to three members
+                if (kv.second.size() - k < 2) break;
+                const int gid = net.n_launch_groups++;
+                for (size_t q = k; q < std::min(kv.second.size(), k + 3); ++q) { grp[kv.second[q]] = gid; sec[kv.second[q]].launch_group = gid; sec[kv.second[q]].shared_in = true; }
+            }
+        }
+        std::vector<char> done(n, 0);
+        auto ready = [&](size_t i) {
+            for (int t : reads(sec[i])) { auto it = t >= 0 ? producer.find(t) : producer.end(); if (it != producer.end() && it->second != (int)i && !done[it->second]) return false; }
+            return true;
+        };
+        std::vector<Op> order;
+        while (order.size() < n) {
+            bool progressed = false;
+            for (size_t i = 0; i < n && !progressed; ++i) {
+                if (done[i] || !ready(i)) continue;
+                std::vector<size_t> members{i};
+                if (grp[i] >= 0) {
+                    members.clear();
+                    bool all = true;
+                    for (size_t q = 0; q < n; ++q) if (grp[q] == grp[i]) { members.push_back(q); all = all && !done[q] && ready(q); }
+                    if (!all) continue;
+                }
+                for (size_t q : members) { order.push_back(sec[q]); done[q] = 1; }
+                progressed = true;
+            }
+            if (!progressed) {                               // (cannot happen with HRNet's fuse layers; keep the reference's order rather than loop)
+                for (size_t i = 0; i < n; ++i) { sec[i].launch_group = net.ops[begin + i].launch_group; sec[i].shared_in = false; }
+                return;
+            }
+        }
+        std::copy(order.begin(), order.end(), net.ops.begin() + begin);
+    }
+
     bool build() {
         const sncal_hrnet_desc& d = net.desc;
         const std::string P = "model.";
@@ -365,6 +427,7 @@ struct Builder {
                         for (int b = 0; b < d.num_blocks[si]; ++b) xs[br] = basic_block(fmt("%s.branches.%d.%d", mn.c_str(), br, b), xs[br]);
                 }
                 std::vector<int> out(nb);
+                const size_t fuse_begin = net.ops.size();
                 for (int i = 0; i < nb; ++i) {                       // hrnet.py:229-244
                     int acc = xs[i];
                     const bool has_up = i < nb - 1;
@@ -389,6 +452,7 @@ struct Builder {
                     }
                     out[i] = acc;
                 }
+                schedule_fuse_section(fuse_begin);
                 xs = out;
             }
             ys = xs;
@@ -1449,6 +1513,40 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
             *done = rc == SNCAL_OK;
             return rc;
         }
+    }
+    if (ops[0].shared_in) {
+        // the chain-starting stride-2 convolutions of one input tensor (schedule_fuse_section): one launch, tile-major (conv.hpp)
+        if (!net.x3_generic) return SNCAL_OK;                 // (the other engines run them one by one)
+        ConvSharedParams sp;
+        memset(&sp, 0, sizeof(sp));
+        const ConvVariant* vs[3] = {nullptr, nullptr, nullptr};
+        size_t lds_s = 0;
+        unsigned ipt = 0;
+        for (int i = 0; i < n; ++i) {
+            size_t l = 0;
+            const int rc = prepare_conv(net, ops[i], sb, ws, sp.p[i], vs[i], l);
+            if (rc) return rc;
+            bool skip_f32 = false;
+            sp.p[i].out_twin = producer_twin(net, ops[i].out, sb, ws, &skip_f32);
+            if (sp.p[i].out_twin && skip_f32) sp.p[i].out = nullptr;
+            const ConvVariant* v = vs[i];
+            const bool ok = ops[i].in == ops[0].in && v->ks == 3 && v->stride == 2 && v->ni == 2 && v->g == 3 && (v->mi == 6 || v->mi == 3) &&
+                            sp.p[i].tiles_x == sp.p[0].tiles_x && sp.p[i].tiles_y == sp.p[0].tiles_y && sp.p[i].twf == sp.p[0].twf;
+            if (!ok) return SNCAL_OK;                          // *done stays false: one by one
+            sp.mi[i] = v->mi;
+            sp.first[i] = ipt;
+            ipt += (unsigned)sp.p[i].nblk;
+            lds_s = std::max(lds_s, l);
+        }
+        for (int i = n; i < 4; ++i) sp.first[i] = ipt;
+        sp.n = n;
+        sp.tiles = (unsigned)(sp.p[0].tiles_x * sp.p[0].tiles_y * sb);
+        sp.tiles_per_xcd = (sp.tiles + 7) / 8;
+        launch_conv_shared_s2_x3(sp, 8u * sp.tiles_per_xcd * ipt, lds_s, stream);
+        SNCAL_CHECK_LAUNCH();
+        if (net.profiling) for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, vs[i], i > 0);
+        *done = true;
+        return SNCAL_OK;
     }
     ConvGroupParams gp;
     memset(&gp, 0, sizeof(gp));

@@ -564,6 +564,36 @@ __device__ __forceinline__ void log_so3(const double* R, double* r) {       // c
     r[0] = a[0] * q; r[1] = a[1] * q; r[2] = a[2] * q;
 }
 
+// The two maps of a rotation vector with the angle and its sine / cosine given (ONE sincos for both, pose_normal_eq): the same
+// formulas as exp_so3 / left_jacobian_so3
+struct RotAngle { double th, sn, cs; };
+__device__ __forceinline__ RotAngle rot_angle(const double* w) {
+    RotAngle a;
+    a.th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    sincos(a.th, &a.sn, &a.cs);
+    return a;
+}
+__device__ __forceinline__ void exp_so3_a(const double* w, const RotAngle& q, double* E) {
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    mul33(K, K, K2);
+    double a, b;
+    if (q.th < 1e-8) { a = 1.0; b = 0.5; }
+    else { a = q.sn / q.th; b = (1 - q.cs) / (q.th * q.th); }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + b * K2[i];
+}
+__device__ __forceinline__ void left_jacobian_so3_a(const double* w, const RotAngle& q, double* J) {
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    mul33(K, K, K2);
+    double a, b;
+    if (q.th < 1e-6) { a = 0.5; b = 1.0 / 6.0; }
+    else { a = (1 - q.cs) / (q.th * q.th); b = (q.th - q.sn) / (q.th * q.th * q.th); }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + b * K2[i];
+}
+
 // exp(r + d) ~ exp(J_l(r) d) exp(r)
 __device__ __forceinline__ void left_jacobian_so3(const double* w, double* J) {
     const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
@@ -706,16 +736,34 @@ __device__ void sym_solve6(const double (&A)[6][6], const double (&b)[6], double
 }
 
 // normal equations of the pose problem at x = [rvec, tvec]: A = J^T J, g = J^T r, S = |r|^2, rinf = |r|_inf (all wave-uniform)
+// `rc` (optional): the rotation of x -- angle, sine, cosine, matrix.  A call with want_j = false FILLS it; a call with want_j = true and
+// rc->valid USES it instead of recomputing: lm_solver_pose linearises an accepted step at exactly the point it has just evaluated, and
+// the sine / cosine / matrix of the rotation vector were 40 % of that evaluation's clocks (SNCAL_LM_TIMING: 5.3k clk per Jacobian
+// evaluation, 2.2k per trial on the 8-point fit).
+struct RotCache { RotAngle q; double R[9]; bool valid; };
 template <int W = 64>
 __device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const double* X, double u, double v, bool want_j,
-                               double (&A)[6][6], double (&g)[6], double& S, double& rinf) {
+                               double (&A)[6][6], double (&g)[6], double& S, double& rinf, RotCache* rc = nullptr) {
     const int lane = threadIdx.x & 63;
     const bool in = (mask >> lane) & 1;
     double R[9], Jl[9];
-    exp_so3(x, R);
+    RotAngle q;
+    if (rc != nullptr && want_j && rc->valid) {
+        q = rc->q;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = rc->R[i];
+    } else {
+        q = rot_angle(x);
+        exp_so3_a(x, q, R);
+        if (rc != nullptr) {
+            rc->q = q; rc->valid = true;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rc->R[i] = R[i];
+        }
+    }
     double ju[6], jv[6], ru, rv, xn, yn;
     if (want_j) {
-        left_jacobian_so3(x, Jl);
+        left_jacobian_so3_a(x, q, Jl);
         pose_rows_rvec(R, Jl, x + 3, k.fx, k.fy, k.cx, k.cy, X, u, v, ju, jv, ru, rv, xn, yn);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -828,6 +876,12 @@ __device__ __attribute__((noinline)) LmPose lm_solver_pose_fn(u64 mask, LmPose i
 #pragma unroll
     for (int i = 0; i < 6; ++i) D[i] = A[i][i];
     double lam = 1.0, lc = 0.75;
+#ifdef SNCAL_LM_TIMING
+    unsigned long long tq[5] = {0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define LM_LAP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tq[k] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define LM_LAP(k) do {} while (0)
+#endif
     for (int it = 0;;) {
         double Ap[6][6], d[6], xd[6];
 #pragma unroll
@@ -840,10 +894,14 @@ __device__ __attribute__((noinline)) LmPose lm_solver_pose_fn(u64 mask, LmPose i
             if (F.ok) chol6_apply(F, g, d);
             else sym_solve6(Ap, g, d);                // not positive definite: the eigen-decomposition fallback (cv::solve DECOMP_EIG)
         }
+        LM_LAP(0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) xd[i] = x[i] - d[i];
         double A2[6][6], g2[6], Sd, rinf_d;
-        pose_normal_eq<W>(mask, xd, k, X, u, v, false, A2, g2, Sd, rinf_d);
+        RotCache rc;
+        rc.valid = false;
+        pose_normal_eq<W>(mask, xd, k, X, u, v, false, A2, g2, Sd, rinf_d, &rc);
+        LM_LAP(1);
         double dS = 0, dv_ = 0, dmax = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -863,6 +921,8 @@ __device__ __attribute__((noinline)) LmPose lm_solver_pose_fn(u64 mask, LmPose i
             nu = fmin(fmax(nu, 2.0), 10.0);
             if (lam == 0.0) {
                 double mx = DBL_EPS;
+                // (lambda = 0 means the step's matrix WAS A, and keeping its factor for here would save this factorisation -- measured: no
+                // gain, and the longer-lived factor pushed the function into scratch memory: 3.1 -> 4.3 us per iteration on a 31-point fit)
                 Chol6 C;
                 chol6_factor(A, C);
                 if (C.ok) {
@@ -883,13 +943,20 @@ __device__ __attribute__((noinline)) LmPose lm_solver_pose_fn(u64 mask, LmPose i
             }
             lam *= nu;
         }
+        LM_LAP(2);
         if (Sd < S) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) x[i] = xd[i];
-            pose_normal_eq<W>(mask, x, k, X, u, v, true, A, g, S, rinf);
+            pose_normal_eq<W>(mask, x, k, X, u, v, true, A, g, S, rinf, &rc);      // (x = xd: the rotation the trial has just built)
         }
+        LM_LAP(3);
         ++it;
-        if (!(it < max_iters && dmax >= eps && rinf >= eps)) break;
+        if (!(it < max_iters && dmax >= eps && rinf >= eps)) {
+#ifdef SNCAL_LM_TIMING
+            if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) printf("LM W=%d its %d: clocks per iteration: solve %.0f trial %.0f gain+inverse %.0f accept+J %.0f\n", W, it, (double)tq[0] / it, (double)tq[1] / it, (double)tq[2] / it, (double)tq[3] / it);
+#endif
+            break;
+        }
     }
     exp_so3(x, R);
     LmPose out;

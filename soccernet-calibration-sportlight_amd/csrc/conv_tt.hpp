@@ -39,7 +39,7 @@ struct TTParams {
     TTMember m[TT_MAX_MEMBERS];
     const TTItem* items;            // grouped by XCD (workgroup b runs on XCD b % 8), most expensive member first inside an XCD
     const uint32_t* xcd_first;      // [9] offsets into items
-    unsigned* queue;                // nine zeroed device words owned by the caller's stream: next item per XCD [0..8), teams that have left [8]
+    unsigned* queue;                // sixteen zeroed device words owned by the caller's stream: next item per XCD [0..8), teams that have left per XCD [8..16)
                                     // (the kernel re-arms them; launches that share the words must be ordered on one stream)
     unsigned* range;                // fp16x3: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
     unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null

@@ -123,12 +123,12 @@ __device__ __forceinline__ float x3_join(unsigned hi_pk, unsigned lo_pk) {
 // in the safe direction.  Infinities count; a NaN cannot arise from finite weights (checked at finalize) and finite frames (checked by the
 // layout kernel) without an overflow first.  The bf16 build of the engine has fp32's exponent range: nothing to track.
 __device__ __forceinline__ void x3_track(float& amax, float a, float b) {
-#if SNCAL_X3_F16
+#if SNCAL_X3_F16 && !defined(SNCAL_X3_NO_TRACK)      // (-DSNCAL_X3_NO_TRACK: A/B builds that price the tracker)
     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a)), __builtin_fabsf(b));
 #endif
 }
 __device__ __forceinline__ void x3_track1(float& amax, float a) {
-#if SNCAL_X3_F16
+#if SNCAL_X3_F16 && !defined(SNCAL_X3_NO_TRACK)
     amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
 #endif
 }

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+for rep in 1 2; do
+for lib in "" tools/ab/libsncal_notrack.so tools/ab/libsncal_r4.so; do
+  echo "== lib ${lib:-main}"; SNCAL_LIB_PATH=$lib DEV_TOP=4 timeout 600 python tools/dev_bench.py 64 fp16x3 6 2>&1 | grep -v amdgpu.ids | head -5
+done; done

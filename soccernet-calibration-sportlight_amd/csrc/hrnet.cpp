@@ -1346,6 +1346,10 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
             per_xcd[x].push_back(it);
         }
     }
+    // (Measured and not kept, round 5: the tickets of a member's slice S-way interleaved -- S = 4, 8, 16, 64 -- so that the items that share
+    // halo lines are not drawn at the same instant: 32.87 / 33.06 / 32.95 / 33.10 ms per step of two-team launches against 32.85 in
+    // tile-major order, FETCH_SIZE 434 against 410 MB per launch.  The queue's extra HBM reads over round 4's static deal -- 412 against
+    // 310 MB per grouped launch by PMC -- are not concurrent misses of neighbouring tickets.)
     std::vector<TTItem> flat;
     std::vector<uint32_t> first(9, 0);
     for (int x = 0; x < 8; ++x) { first[x] = (uint32_t)flat.size(); flat.insert(flat.end(), per_xcd[x].begin(), per_xcd[x].end()); }

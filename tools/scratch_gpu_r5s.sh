@@ -1,9 +1,8 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_range_guard_gpu.py -m gpu -q -s 2>&1 | grep -v "^$" | tail -25
-SNCAL_BENCH_DIAG=nosolve timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | grep diag
-SNCAL_LIB_PATH=tools/ab/libsncal_r4.so SNCAL_BENCH_DIAG=nosolve timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | grep diag
-SNCAL_BENCH_DIAG=nosolve timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | grep diag
-SNCAL_LIB_PATH=tools/ab/libsncal_r4.so SNCAL_BENCH_DIAG=nosolve timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | grep diag
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5s_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r5s_pytest.log
+# round 5: the PMC passes of the final build (traffic + matrix-pipe utilisation), then the bench lines and the kernel stats
+export PMC_B=64 PMC_DTYPE=fp16x3
+bash tools/pmc_pass.sh r05v26_x3 FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" 2>&1 | tail -12
+cd $GRAFT_REPO_ROOT
+python tools/pmc_traffic.py gpurun_out/r05v26_x3 r05v26 64 > gpurun_out/r05v26_x3/traffic.md 2>&1; tail -24 gpurun_out/r05v26_x3/traffic.md
+python tools/pmc_mfma.py gpurun_out/r05v26_x3 r05v26_fp16x3 2>&1 | tail -14
+cp profiles/pmc_traffic.json profiles/r05v26_pmc_hbm_traffic.md profiles/r05v26_fp16x3_pmc_mfma_util.* gpurun_out/r05v26_x3/ 2>/dev/null

@@ -42,6 +42,7 @@ struct TTParams {
     unsigned* queue;                // sixteen zeroed device words owned by the caller's stream: next item per XCD [0..8), teams that have left per XCD [8..16)
                                     // (the kernel re-arms them; launches that share the words must be ordered on one stream)
     unsigned* range;                // fp16x3: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
+    int lazy;                       // 1: small launch -- a workgroup draws its next ticket only when its pair is done (conv_tt_body.inc)
     unsigned long long* trace;      // tuning aid (SNCAL_TT_TRACE=<file>): 256 s_memtime stamps per team, or null
     int ablate;                     // tuning aid (SNCAL_TT_ABLATE, timing only, results invalid): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA
 };

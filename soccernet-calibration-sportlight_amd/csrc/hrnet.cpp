@@ -126,7 +126,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
-    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; };
+    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; int lazy = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
@@ -1360,6 +1360,8 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     SNCAL_CHECK_HIP(hipMemcpy(out.items, flat.data(), flat.size() * sizeof(TTItem), hipMemcpyHostToDevice));
     SNCAL_CHECK_HIP(hipMemcpy(out.first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     out.n_wgs = n_wgs;
+    // fewer than 8 pairs of items per workgroup in an XCD's list: the kernel's three-pairs-ahead ticket pipeline would starve most workgroups
+    out.lazy = flat.size() < (size_t)3 * (size_t)n_wgs ? 1 : 0;      // fewer than 1.5 pairs per workgroup
     return SNCAL_OK;
 }
 
@@ -1406,7 +1408,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }
-    tp.items = it->second.items; tp.xcd_first = it->second.first;
+    tp.items = it->second.items; tp.xcd_first = it->second.first; tp.lazy = it->second.lazy;
     { const int rc = ensure_tickets(&net, stream); if (rc) return rc; }
     tp.queue = net.d_tickets + 32;
     // tuning aid: SNCAL_TT_TRACE=<file> dumps the per-team phase timestamps of the LAST launch with 3 members

@@ -22,6 +22,12 @@
 //     (w_ready / w_done per step, x_ready / x_free per tile), the eight multiplying waves meet only at the mid tile;
 //   * the residual is the centre of the x halo (registers, read before the halo region is handed back), the next tile's halo lands
 //     under conv2, the output is stored straight from the accumulators as the split twin the next block reads and / or as fp32.
+//   * (round 5) the frames are tiled as ONE stack of N (H + 1) rows and a workgroup walks RUNS of up to eight tiles down a 14-column
+//     strip, keeping the four x rows and two mid rows a tile shares with the one above it in LDS (kernel body: "Geometry"): 576 -> 544
+//     tile rows per 64 frames of 135 rows, conv1 on 16 instead of 18 mid rows for three tiles in four, 20 % fewer halo requests;
+//     632 -> 595 us per block on the same box, outputs bit for bit the same.  What the phase trace shows is left: the multiply loops run
+//     at 257 clk per sub-step (12 MFMAs per SIMD = 192 clk nominal) with every DMA switched off (SNCAL_BBX_DBG=6: 27.1k against 28.5k clk
+//     per tile) -- 40 ds_read_b128 per sub-step and CU are 160 of those clocks on the LDS port; 3 x J register blocking at J = 2.
 // Arithmetic: hi = rne16(v), lo = rne16(v - hi); mid is split exactly like a tensor that conv_tt would have written, so the block
 // equals conv1 -> twin -> conv2 of the two-kernel path up to the summation order inside the matrix unit.
 #include "bblockx3.hpp"
@@ -56,9 +62,16 @@ constexpr int NW = 8;                               // multiplying waves (two pe
 constexpr int J1 = (MH + NW - 1) / NW, J2 = TH / NW;                          // pixel fragments (tile rows) per wave: conv1 (at most), conv2
 constexpr int NSUB = 3 * BBX_STEPS - 1;             // sub-steps of a convolution: (cross u0, cross u1, main) per step, no cross for the zero unit
 static_assert(XH * X_PITCH <= X_PLANE && (2 * BBX_STEPS) % RING_SLOTS == 0 && TH % NW == 0 && J1 == J2 + 1 && LDS_BYTES <= 160 * 1024, "layout");
-enum { C_WREADY = 0, C_XREADY = 2, C_XFREE = 3, C_MID = 4, C_TKNOWN = 5, C_WDONE = 8, C_TILE = 16 };       // C_TILE + (round & 3): the round's tile, or TILE_END
+enum { C_WREADY = 0, C_XREADY = 2, C_XFREE = 3, C_MID = 4, C_TKNOWN = 5, C_MCOPY = 6, C_WDONE = 8, C_TILE = 16 };       // C_TILE + (round & 3): the round's tile, or TILE_END
 constexpr unsigned TILE_END = 0xffffffffu;          // C_WDONE + w: steps wave w has finished reading (a SUM over waves
                                                                                        // would let seven fast waves vouch for a slow one)
+constexpr unsigned TILE_CONT = 0x40000000u;         // flag in a tile word: the tile directly BELOW the workgroup's previous one (see "runs")
+// A continuing tile keeps what it shares with the tile above: x halo rows 16..19 become rows 0..3 (LDS slots 0..383 of either plane, whole
+// 1 KB pieces; the piece that straddles rows 3 | 4 is simply fetched again) and mid rows 16, 17 become rows 0, 1.
+constexpr int KEEP_XROWS = 4, KEEP_PIECES = KEEP_XROWS * XW * 6 / 64, KEEP_SRC = (XH - KEEP_XROWS) * X_PITCH;
+constexpr unsigned OOB = 0xfffffe00u;               // a buffer offset beyond any tensor the launcher accepts (reads return zero, stores are dropped)
+constexpr int RUN_MAX = 8;                          // longest run of vertically adjacent tiles a workgroup takes with one ticket
+static_assert(KEEP_PIECES == 6 && KEEP_SRC + KEEP_PIECES * 1024 <= XH * X_PITCH && KEEP_PIECES * 1024 <= KEEP_XROWS * X_PITCH, "kept halo rows");
 
 // One LDS-DMA piece (64 lanes x 16 bytes -> 1 KB at LDS byte address `lds_addr`) as inline assembly: hipcc's wait-count pass does not
 // see it, so the loader's counter polls are not preceded by vmcnt(0); every wait of this kernel is explicit.
@@ -85,17 +98,29 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
     if (tid < 96) s_bias[tid] = tid < 48 ? p.b1[tid] : p.b2[tid - 48];
     __syncthreads();
 
-    // tiles of this workgroup: the launch's tiles are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8); the
-    // workgroups of an XCD take the tiles of its range IN ORDER from a ticket counter of the XCD (p.ticket[xcd]), so neighbouring halos
-    // meet in one L2 -- and a workgroup whose CU another stream's work holds for a while (the camera solves of the previous batch)
-    // simply takes fewer tiles.  With the static deal of rounds 3 / 4 (tile t_lo + wx + round * per_xcd) such a workgroup started late
-    // and the launch lasted until it had walked its whole share: +4 % on the blocks that run beside the solves.  The halo wave takes the
-    // ticket (it is a round ahead of everybody) and publishes the tile through LDS; the last workgroup to run dry re-arms the counters.
+    // Geometry.  The frames are walked as ONE image of N (H + 1) rows -- frame n at rows n (H + 1) .., one separator row between frames that
+    // reads as zeros and is never stored: with per-frame tiles a 135-row frame cost 9 x 16 = 144 tile rows (6.25 % of the tiles' rows empty),
+    // stacked it costs 136.  Tile (ys, tx) covers stacked rows 16 ys .. + 15 and columns 14 tx .. + 13.
+    // Tiles of this workgroup: the tile ROWS are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8); the workgroups of
+    // an XCD draw RUNS from the XCD's ticket counter (p.ticket[xcd]): a run = up to RUN_MAX vertically adjacent tiles of one 14-column strip,
+    // walked downwards.  From the second tile of a run on, conv1 computes 16 mid rows instead of 18 (two per wave: the 18-row tile gives two
+    // waves three rows and the SIMDs that host them set conv1's pace, 630 against 504 MFMAs) and the halo wave fetches 28 pieces per plane
+    // instead of 34.  Runs are dealt row-block-major, strip-minor, so the workgroups of an XCD walk neighbouring strips side by side and
+    // the column overlap of their halos meets in the XCD's L2.  Long runs leave a long tail: the run length halves (8, 4, 2, 1) towards the
+    // end of the XCD's range, each length while at least one run per workgroup of it is left ("guided" deal); launches with less than a
+    // handful of tiles per workgroup come out as single tiles.  A workgroup whose CU another stream's work holds for a while (the camera
+    // solves of the previous batch) simply takes fewer runs (round 5; the static deal of rounds 3 / 4 made the launch wait for it: +4 %).
+    // The halo wave takes the ticket (it is a round ahead of everybody) and publishes the tiles through LDS; the last workgroup to run dry
+    // re-arms the counters.
     const int xcd = (int)blockIdx.x & 7;
-    const int n_tiles = p.N * p.tiles_y * p.tiles_x;
-    const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
+    const int h1 = p.H + 1, rows_s = p.N * h1;                     // stacked rows (the last separator is never reached by a valid pixel)
+    const int tiles_ys = (rows_s - 1 + TH - 1) / TH;
+    const int y_lo = (int)((long)tiles_ys * xcd / 8), y_hi = (int)((long)tiles_ys * (xcd + 1) / 8);
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)smem;
     const unsigned img_twin = (unsigned)(p.H * p.W * 192);
+    // stacked row v -> (frame, row in frame): v / h1 by multiplication (exact for v h1 < 2^32: the launcher bounds N)
+    const unsigned h1_magic = p.h1_magic;
+    auto frame_of = [&](unsigned v) -> unsigned { return __umulhi(v, h1_magic); };
 
     auto publish = [&](int word, unsigned v) { if (lane == 0) __hip_atomic_store(ctrl + word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (wave == NW + 1) {
@@ -103,14 +128,73 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
         // One tile's x halo per round: 34 + 34 requests that come from HBM.  It has a wave (= a request queue) of its own: requests of one
         // wave complete in order, and riding with the weight stream -- all at once, or a few per step -- the halo's HBM latency stood in
         // front of every weight step that followed it (conv2: 8k clk of MFMAs took 18k / 23k clk, phase trace).
+        // small launches (fewer than 8 tile rows per XCD: up to batch 7 at 540p): whole tile rows per XCD are too coarse a cut (batch 1: nine
+        // tile rows for eight XCDs, one of them with two rounds of tiles) -- the row-major tile list is cut into eight equal shares instead
+        const bool flat = tiles_ys < 64;
+        const int n_tiles = tiles_ys * p.tiles_x;
+        const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
+        // phases of the XCD's deal: rows_of[k] tile rows in runs of RUN_MAX >> k tiles
+        int rows_of[4];
+        {
+            const int wgs = ((int)gridDim.x - xcd + 7) / 8;
+            int rem = y_hi - y_lo;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int L = RUN_MAX >> k, keep = (wgs * L + p.tiles_x - 1) / p.tiles_x;
+                rows_of[k] = p.run_max >= L && rem > keep ? (rem - keep) / L * L : 0;
+                rem -= rows_of[k];
+            }
+            rows_of[3] = rem;
+        }
+        const i32x4_t rs = raw_rsrc(p.x, (unsigned)p.N * img_twin);
+        int k = 0, len = 0, row0 = 0, strip = 0;
+        unsigned n_cont = 0;
+        bool prev_cont = false;
         for (int ti = 0;; ++ti) {
-            unsigned tk = 0;
-            if (lane == 0) tk = atomicAdd(p.ticket + xcd, 1u);
-            const int t = t_lo + __builtin_amdgcn_readfirstlane((int)tk);
-            const bool dry = t >= t_hi;
+            if (k == len) {                                                               // the next run
+                unsigned tk = 0;
+                if (lane == 0) tk = atomicAdd(p.ticket + xcd, 1u);
+                int r = __builtin_amdgcn_readfirstlane((int)tk);
+                row0 = y_lo; len = 0; k = 0;
+                if (flat) {                                                               // single tiles of the XCD's share of the row-major tile list
+                    r += t_lo;
+                    if (r < t_hi) { len = 1; row0 = r / p.tiles_x; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int L = RUN_MAX >> q, runs = rows_of[q] / L * p.tiles_x;
+                        if (len == 0) {
+                            if (r < runs) { len = L; row0 += r / p.tiles_x * L; }
+                            else { r -= runs; row0 += rows_of[q]; }
+                        }
+                    }
+                }
+                strip = r % p.tiles_x;
+            }
+            const bool dry = len == 0;
             // (slot ti & 3 last held round ti - 4; every reader is in round ti - 1 or later: the XFREE wait below)
-            publish(C_TILE + (ti & 3), dry ? TILE_END : (unsigned)t);
+            publish(C_TILE + (ti & 3), dry ? TILE_END : (unsigned)((row0 + k) * p.tiles_x + strip) | (k > 0 ? TILE_CONT : 0u));
             publish(C_TKNOWN, (unsigned)ti + 1u);
+            if (prev_cont) {
+                // tile ti - 1 continues tile ti - 2: the upper tile's last two mid rows are the lower tile's first two.  Moved HERE, while the
+                // multiplying waves are in conv1 of tile ti - 1 (they moved them themselves at first: +1k clk on waves 6 / 7 in front of the mid
+                // barrier): every wave is done with conv2 of tile ti - 2, and nobody writes or reads mid before C_MCOPY says so
+                const unsigned need = 2u * BBX_STEPS * (unsigned)(ti - 1);
+                while (__builtin_amdgcn_ballot_w64((int)(poll(ctrl + C_WDONE + (lane & (NW - 1))) - need) >= 0) != ~0ull) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                static_assert(2 * M_PITCH == 3 * 1024, "two mid rows are 3 KB per plane");
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    u32x4 part[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) part[i] = *reinterpret_cast<const u32x4*>(smem + OFF_M + pl * M_PLANE + (MH - 2) * M_PITCH + i * 1024 + lane * 16);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(smem + OFF_M + pl * M_PLANE + i * 1024 + lane * 16) = part[i];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                publish(C_MCOPY, ++n_cont);
+                prev_cont = false;
+            }
             if (dry) {
                 if (lane == 0 && atomicAdd(p.ticket + 8, 1u) == gridDim.x - 1u) {     // every workgroup holds its one failing ticket
 #pragma unroll
@@ -119,24 +203,42 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
                 }
                 break;
             }
-            const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
-            const int oy0 = ty * TH - 2, ox0 = tx * TW - 2;
-            const i32x4_t rs = raw_rsrc(reinterpret_cast<const char*>(p.x) + (size_t)n * img_twin, img_twin);
+            const int oy0 = (row0 + k) * TH - 2, ox0 = strip * TW - 2;
             if (ti > 0) spin_until(ctrl + C_XFREE, (unsigned)NW * (unsigned)ti);          // everyone has read its residual out of the old halo
-            for (int piece = 0; piece < X_PIECES; ++piece) {
+            int piece0 = 0;
+            if (k > 0) {                                                                  // the four rows shared with the tile above stay in LDS
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {                                          // (a plane at a time: 24 registers)
+                    u32x4 keep[KEEP_PIECES];
+#pragma unroll
+                    for (int i = 0; i < KEEP_PIECES; ++i)
+                        keep[i] = *reinterpret_cast<const u32x4*>(smem + OFF_X + pl * X_PLANE + KEEP_SRC + i * 1024 + lane * 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (read before the requests below overwrite rows 16..19)
+#pragma unroll
+                    for (int i = 0; i < KEEP_PIECES; ++i)
+                        *reinterpret_cast<u32x4*>(smem + OFF_X + pl * X_PLANE + i * 1024 + lane * 16) = keep[i];
+                }
+                piece0 = KEEP_PIECES;
+            }
+            for (int piece = piece0; piece < X_PIECES; ++piece) {
                 // LDS slot q of a plane = pixel q / 6 of the 20 x 18 halo (row-major), 16-byte slot q % 6 = (group, half) of its 48 channels;
                 // the twin keeps [hi half 0 | hi half 1 | lo half 0 | lo half 1] per group: hi plane from +0 / +16, lo plane from +32 / +48
                 const unsigned q = (unsigned)(piece * 64 + lane);
                 const unsigned px = (q * 43691u) >> 18, sl = q - px * 6u;                  // q / 6 for q < 2^16
                 const unsigned row = (px * 3641u) >> 16, col = px - row * 18u;            // px / 18 for px < 2^12
-                const int iy = oy0 + (int)row, ix = ox0 + (int)col;
-                const bool ok = (px < (unsigned)(XH * XW)) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                const unsigned voff = ok ? (unsigned)((iy * p.W + ix) * 192) + (sl >> 1) * 64u + (sl & 1u) * 16u : 0x80000000u;
+                const int vs = oy0 + (int)row, ix = ox0 + (int)col;
+                const unsigned n = frame_of((unsigned)(vs < 0 ? 0 : vs));
+                const int iy = vs - (int)n * h1;
+                const bool ok = (px < (unsigned)(XH * XW)) & (vs >= 0) & (n < (unsigned)p.N) & (iy < p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned voff = ok ? n * img_twin + (unsigned)((iy * p.W + ix) * 192) + (sl >> 1) * 64u + (sl & 1u) * 16u : OOB;
+                if (p.dbg & 4) continue;
                 dma_piece(rs, lds0 + OFF_X + piece * 1024, voff, 0u);
                 dma_piece(rs, lds0 + OFF_X + X_PLANE + piece * 1024, voff, 32u);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             publish(C_XREADY, (unsigned)ti + 1u);
+            prev_cont = k > 0;
+            ++k;
         }
         return;
     }
@@ -159,7 +261,8 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
                 const i32x4_t rs = s < BBX_STEPS ? rs_w1 : rs_w2;
                 const unsigned src = (unsigned)((s < BBX_STEPS ? s : s - BBX_STEPS) * BBX_STEP_BYTES);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) dma_piece(rs, lds0 + OFF_RING + slot * BBX_STEP_BYTES + i * 1024, (unsigned)(lane * 16), src + i * 1024);
+                for (int i = 0; i < 6; ++i)
+                    if (!(p.dbg & 2) || g < 4u) dma_piece(rs, lds0 + OFF_RING + slot * BBX_STEP_BYTES + i * 1024, (unsigned)(lane * 16), src + i * 1024);
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 if (g >= 1u) publish(C_WREADY, g - 1u);
             }
@@ -260,20 +363,35 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
     float amax = 0.f;                                  // range tracker of the mid and output splits (x3.hpp)
     auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
 
+    bool at_cont = false;
+    unsigned n_cont = 0;                               // continuing tiles so far
     for (int ti = 0;; ++ti) {
         spin_until(ctrl + C_TKNOWN, (unsigned)ti + 1u);
         const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane((int)poll(ctrl + C_TILE + (ti & 3)));
         if (tu == TILE_END) break;
-        const int t = (int)tu;
-        const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, n = t / (p.tiles_x * p.tiles_y);
-        const int oy0 = ty * TH, ox0 = tx * TW;
+        const bool cont = (tu & TILE_CONT) != 0u;
+        const int t = (int)(tu & ~TILE_CONT);
+        const int tx = t % p.tiles_x, ys = t / p.tiles_x;
+        const int oy0 = ys * TH, ox0 = tx * TW;                       // (oy0: stacked row)
         const unsigned gs = (unsigned)ti * 2u * BBX_STEPS;
         if (tracing) tprev = __builtin_amdgcn_s_memtime();
         init_acc(0);
         spin_until(ctrl + C_XREADY, (unsigned)ti + 1u);                   // this tile's halo has landed
         lap(0);
-        // conv1: mid rows f = wave + 8 j (waves 0 and 1 own three, the others two)
-        if (wave + NW * (J1 - 1) < MH)
+        // conv1.  First tile of a run: mid rows f = wave + 8 j of all 18 (waves 0 and 1 own three, the others two); continuing tile: rows
+        // 0, 1 are the tile above's rows 16, 17 (copied below), f = 2 + wave + 8 j of the 16 new ones
+        const int f0 = cont ? 2 : 0;
+        if (cont != at_cont) {                                        // the conv1 fragment addresses follow f0 (a run's second tile, a new run's first)
+            const unsigned d = cont ? 2u * X_PITCH : 0u - 2u * X_PITCH;
+#pragma unroll
+            for (int j = 0; j < J1; ++j) {
+                bc1[j] += d;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bh1[j][i] += d;
+            }
+            at_cont = cont;
+        }
+        if (!cont && wave + NW * (J1 - 1) < MH)
             conv(std::integral_constant<int, J1>{}, std::integral_constant<int, X_PITCH>{}, std::integral_constant<int, 0>{}, bc1, bh1, gs);
         else
             conv(std::integral_constant<int, J1 - 1>{}, std::integral_constant<int, X_PITCH>{}, std::integral_constant<int, 0>{}, bc1, bh1, gs);
@@ -290,13 +408,17 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
                 for (int e = 0; e < 4; ++e) res[j][cb][e] = (float)rl[e] + (float)rh[e];
             }
         signal(C_XFREE);
-        // mid = ReLU(conv1) as hi / lo planes; positions outside the image are conv2's zero padding
+        // continuing tile: mid rows 0, 1 are the tile above's rows 16, 17, moved by the halo wave during conv1 (long done: the poll is a formality)
+        if (cont) spin_until(ctrl + C_MCOPY, ++n_cont);
+        // mid = ReLU(conv1) as hi / lo planes; positions outside the image (separator rows between frames included) are conv2's zero padding
 #pragma unroll
         for (int j = 0; j < J1; ++j) {
-            const int f = wave + NW * j;
+            const int f = f0 + wave + NW * j;
             if (f < MH) {
-                const int iy = oy0 - 1 + f, ix = ox0 - 1 + ln;
-                const bool inimg = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const int vs = oy0 - 1 + f, ix = ox0 - 1 + ln;
+                const unsigned n = frame_of((unsigned)(vs < 0 ? 0 : vs));
+                const int iy = vs - (int)n * h1;
+                const bool inimg = (vs >= 0) & (n < (unsigned)p.N) & (iy < p.H) & ((unsigned)ix < (unsigned)p.W);
 #pragma unroll
                 for (int cb = 0; cb < 3; ++cb) {
                     float v[4];
@@ -318,18 +440,20 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
         conv(std::integral_constant<int, J2>{}, std::integral_constant<int, M_PITCH>{}, std::integral_constant<int, BBX_STEPS % RING_SLOTS>{}, bc2, bh2, gs + BBX_STEPS);
         lap(4);
         // epilogue: + x, ReLU -> split twin (8 + 8 bytes per lane and block: the four lanes of a pixel complete 32-byte halves) and / or fp32
-        const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(p.out_twin ? reinterpret_cast<char*>(p.out_twin) + (size_t)n * img_twin : const_cast<void*>(p.x), 0,
-                                                                                 p.out_twin && !(p.dbg & 1) ? (int)img_twin : 0, 0x00020000);
-        const unsigned img_f32 = (unsigned)(p.H * p.W * p.out_cstride * 4);
-        const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(p.out ? reinterpret_cast<char*>(p.out) + (size_t)n * img_f32 : const_cast<void*>(p.x), 0,
-                                                                                p.out && !(p.dbg & 1) ? (int)img_f32 : 0, 0x00020000);
         const bool has_tw = p.out_twin != nullptr, has_f = p.out != nullptr;
+        const unsigned img_f32 = (unsigned)(p.H * p.W * p.out_cstride * 4);
+        const __amdgpu_buffer_rsrc_t rs_tw = __builtin_amdgcn_make_buffer_rsrc(has_tw ? p.out_twin : const_cast<void*>(p.x), 0,
+                                                                                 has_tw && !(p.dbg & 1) ? (int)((unsigned)p.N * img_twin) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(has_f ? static_cast<void*>(p.out) : const_cast<void*>(p.x), 0,
+                                                                                has_f && !(p.dbg & 1) ? (int)((unsigned)p.N * img_f32) : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < J2; ++j) {
-            const int oy = oy0 + wave + NW * j, ox = ox0 + ln;
-            const bool ok = (ln < TW) & (oy < p.H) & (ox < p.W);
-            const unsigned vt = ok ? (unsigned)((oy * p.W + ox) * 192 + o * 8) : 0x80000000u;
-            const unsigned vf = ok ? (unsigned)(((oy * p.W + ox) * p.out_cstride + p.out_coff + o * 4) * 4) : 0x80000000u;
+            const int vs = oy0 + wave + NW * j, ox = ox0 + ln;
+            const unsigned n = frame_of((unsigned)vs);
+            const int oy = vs - (int)n * h1;
+            const bool ok = (ln < TW) & (n < (unsigned)p.N) & (oy < p.H) & (ox < p.W);
+            const unsigned vt = ok ? n * img_twin + (unsigned)((oy * p.W + ox) * 192 + o * 8) : OOB;
+            const unsigned vf = ok ? n * img_f32 + (unsigned)(((oy * p.W + ox) * p.out_cstride + p.out_coff + o * 4) * 4) : OOB;
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb) {
                 float v[4];
@@ -363,8 +487,30 @@ __global__ __launch_bounds__(64 * (NW + 2)) void bblockx3_kernel(const BBlockX3P
 
 int launch_bblockx3(const BBlockX3Params& p0, hipStream_t s) {
     BBlockX3Params p = p0;
+    // one launch addresses its tensors with 32-bit buffer offsets: more frames than fit go in several launches
+    const size_t img = (size_t)p.H * p.W * (size_t)(p.out && p.out_cstride * 4 > 192 ? p.out_cstride * 4 : 192);
+    const size_t n_max = img ? (size_t)0xf0000000u / img : 0;
+    if (n_max == 0 || (size_t)(p.H + 1) * (p.H + 1) * (n_max < (size_t)p.N ? n_max : (size_t)p.N) >= ((size_t)1 << 32)) {
+        set_error("launch_bblockx3: image too large for 32-bit offsets");
+        return SNCAL_ERR_ARG;
+    }
+    if ((size_t)p.N > n_max) {
+        for (int n0 = 0; n0 < p0.N; n0 += (int)n_max) {
+            BBlockX3Params q = p0;
+            q.N = p0.N - n0 < (int)n_max ? p0.N - n0 : (int)n_max;
+            q.x = static_cast<const char*>(p0.x) + (size_t)n0 * p.H * p.W * 192;
+            if (p0.out_twin) q.out_twin = static_cast<char*>(p0.out_twin) + (size_t)n0 * p.H * p.W * 192;
+            if (p0.out) q.out = p0.out + (size_t)n0 * p.H * p.W * p.out_cstride;
+            const int rc = launch_bblockx3(q, s);
+            if (rc) return rc;
+        }
+        return SNCAL_OK;
+    }
     p.tiles_x = (p.W + TW - 1) / TW;
-    p.tiles_y = (p.H + TH - 1) / TH;
+    p.tiles_y = (p.N * (p.H + 1) - 1 + TH - 1) / TH;
+    p.h1_magic = (unsigned)((((unsigned long long)1 << 32) / (unsigned)(p.H + 1)) + 1ull);
+    static const int run_max = getenv("SNCAL_BBX_RUNS") ? atoi(getenv("SNCAL_BBX_RUNS")) : RUN_MAX;
+    p.run_max = run_max < 1 ? 1 : run_max;
     p.trace = nullptr;
     static const int dbg = getenv("SNCAL_BBX_DBG") ? atoi(getenv("SNCAL_BBX_DBG")) : 0;
     p.dbg = dbg;

@@ -20,8 +20,10 @@ struct BBlockX3Params {
     const float* b2;
     int N, H, W;
     int out_cstride, out_coff;
-    int tiles_x, tiles_y;   // filled by the launcher
-    int dbg;                // tuning aid (SNCAL_BBX_DBG): 1 = drop the output stores (timing only)
+    int tiles_x, tiles_y;   // filled by the launcher (tiles_y: tile rows of the N (H + 1) stacked rows)
+    unsigned h1_magic;      // filled by the launcher: floor(2^32 / (H + 1)) + 1 (stacked row -> frame by one multiplication)
+    int run_max;            // filled by the launcher: longest run of vertically adjacent tiles per ticket (SNCAL_BBX_RUNS, default 8; 1 = single tiles)
+    int dbg;                // tuning aid (SNCAL_BBX_DBG, timing only -- results are wrong): 1 = drop the output stores, 2 = no weight requests after the first steps, 4 = no halo requests
     unsigned long long* trace;   // tuning aid (SNCAL_BBX_TRACE=<file>): 8 clock sums per wave, or null
     unsigned* range;        // fp16x3: sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp x3_report), or null
     unsigned* ticket;       // nine zeroed device words owned by the caller's stream: tile tickets per XCD [0..8), workgroups that ran dry [8] (re-armed by the kernel)

@@ -11,16 +11,17 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device('cuda:0')
 net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
 net.load_state_dict(seeded_weights('hrnet_w48', 1))
-x = torch.rand((B, 3, 540, 960), device=dev)
+H, W = int(os.environ.get('DEV_H', '540')), int(os.environ.get('DEV_W', '960'))
+x = torch.rand((B, 3, H, W), device=dev)
 if dtype == 'fp8':
     net.calibrate_fp8(x[:8])
 for _ in range(1):
-    net.forward(x, want_heat=False, decode_size=(540, 960))
+    net.forward(x, want_heat=False, decode_size=(H, W))
 torch.cuda.synchronize()
 net.set_profiling(os.environ.get('DEV_NOPROF', '0') != '1')
 t0 = time.time()
 for _ in range(steps):
-    net.forward(x, want_heat=False, decode_size=(540, 960))
+    net.forward(x, want_heat=False, decode_size=(H, W))
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 print(f'B={B} {dtype} subbatch={os.environ.get("SNCAL_SUBBATCH", "64")}: {dt*1e3:.1f} ms/step, {B/dt:.1f} frames/s, {B/dt*507.82e9/1e12:.1f} TFLOP/s (reference-formulation flops)')

@@ -38,6 +38,7 @@ struct HeadParams {
     int HP, NQ, LC;                // padded hidden width (800), HP/32, padded class count (M2*16)
     int tiles_x, tiles_y;          // filled by the launcher
     unsigned tiles_x_magic, tiles_y_magic;   // filled by the launcher: floor(2^32 / d) + 1
+    int stage_folds;               // headx3.hip, filled by the launcher: the folded branches' source boxes of a tile go through LDS once (1) or every lane fetches its taps (0)
     unsigned* range;               // headx3.hip (fp16x3): sticky counter of wavefronts that split a value beyond the fp16 range (x3.hpp), or null
     unsigned long long* trace;     // head32.hip tuning aid (SNCAL_HEAD_TRACE=<file>): 8 phase sums per workgroup, or null
 };

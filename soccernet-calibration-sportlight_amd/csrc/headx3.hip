@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
         dma_piece(rs_w1h, lds0 + OFF_W1H + wave * 1024, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024));
         dma_piece(rs_w1l, lds0 + OFF_W1L + wave * 1024, (unsigned)(lane * 16), (unsigned)((q * RB * 2 + wave) * 1024));
     };
+    unsigned long long tpro[2] = {0, 0}, tpro_prev = t_begin;      // tuning aid: prologue split (slot 6: set-up + first requests, slot 7: direct fragments + box wait)
+    auto lap_pro = [&](int k) { if (p.trace) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tpro[k] += now - tpro_prev; tpro_prev = now; } };
     issue_boxes(0);
     issue_w0(0);
 
@@ -164,12 +166,65 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
     // (A branch-free form of this loop -- every k-step a four-tap blend, the loads of 4 + 4 + 2 + 2 + 1 k-steps in flight together --
     // was measured in round 4: the prologue stayed at ~30k clocks of a workgroup's ~166k.  It is bound by the number of cache lines the
     // taps touch (64 B per pixel, tap and k-step), not by 13 serial trips to HBM.)
+    // Round 5: the folded branches' taps come out of LDS.  A tile of 4 x 32 pixels blends 72 float4 per lane out of a 4 x 18 (x2 branch) and a
+    // 3 x 10 (x4 branch) pixel box of the sources; fetched per lane those are 9 KB of requests per pixel row and k-step through the vector
+    // memory path, four lanes to a cache line at best -- the prologue was 30k of a workgroup's 166k clocks and bound by exactly that count
+    // (round 4).  Now the two boxes (<= 26 KB) are requested once per workgroup as LDS-DMA pieces into stage-1 weight buffer 1, which is idle
+    // until the top of slice 0, while the direct tensor's fragments are fetched, and the blends read LDS.
     bf16x8 bDh[KS], bDl[KS];
     const float* direct = reinterpret_cast<const float*>(p.direct);
+    int f_iy0[HEAD_MAX_FOLD], f_ix0[HEAD_MAX_FOLD], f_bw[HEAD_MAX_FOLD], f_off[HEAD_MAX_FOLD];
+    if (p.stage_folds) {
+        int off = 0;
+        const int y0c = min(oy0, p.H - 1), y3c = min(oy0 + 3, p.H - 1), x31c = min(ox0 + 31, p.W - 1);
+#pragma unroll
+        for (int f = 0; f < HEAD_MAX_FOLD; ++f) {
+            f_iy0[f] = f_ix0[f] = f_bw[f] = f_off[f] = 0;
+            if (f < p.nfold) {
+                const int iy0 = min((int)(p.fsy[f] * (float)y0c), p.Hf[f] - 1), iy3 = min((int)(p.fsy[f] * (float)y3c), p.Hf[f] - 1);
+                const int ix0 = min((int)(p.fsx[f] * (float)ox0), p.Wf[f] - 1), ix1 = min((int)(p.fsx[f] * (float)x31c), p.Wf[f] - 1);
+                const int nrows = iy3 - iy0 + 1 + (iy3 < p.Hf[f] - 1 ? 1 : 0), bw = ix1 - ix0 + 1 + (ix1 < p.Wf[f] - 1 ? 1 : 0);
+                const unsigned rowb = (unsigned)(bw * p.Cf[f] * 4), total = (unsigned)nrows * rowb;       // (a box row is contiguous in the source)
+                const int npieces = (int)((total + 1023u) / 1024u);
+                const size_t img = (size_t)p.Hf[f] * p.Wf[f] * p.Cf[f] * 4;
+                const i32x4_t rs_f = raw_rsrc(reinterpret_cast<const char*>(p.fold[f]) + (size_t)n * img, (unsigned)img);
+                const unsigned lds_f = (unsigned)(__UINTPTR_TYPE__)(lds_void*)smem + OFF_W0 + W0_BUF + (unsigned)off;
+                for (int i = wave; i < npieces; i += 4) {
+                    const unsigned o = (unsigned)((i * 64 + lane) * 16);
+                    const unsigned row = (o >= rowb ? 1u : 0u) + (o >= 2u * rowb ? 1u : 0u) + (o >= 3u * rowb ? 1u : 0u);      // (<= 4 rows: launcher)
+                    const unsigned voff = o < total ? (unsigned)(((iy0 + (int)row) * p.Wf[f] + ix0) * p.Cf[f] * 4) + (o - row * rowb) : 0x80000000u;
+                    dma_piece(rs_f, lds_f + (unsigned)(i * 1024), voff, 0u);
+                }
+                f_iy0[f] = iy0; f_ix0[f] = ix0; f_bw[f] = bw; f_off[f] = off;
+                off += npieces * 1024;
+            }
+        }
+    }
+    // torch's bilinear order: rows blended in x first, then in y (upsample_add's fp32 path, ops.hip)
+    auto blend8 = [&](const auto* t, int dx, int dy, float lx1, float ly1, float (&v)[8]) __attribute__((always_inline)) {
+        const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+            const float4 t00 = *reinterpret_cast<const float4*>(t + 4 * h4), t01 = *reinterpret_cast<const float4*>(t + dx + 4 * h4);
+            const float4 t10 = *reinterpret_cast<const float4*>(t + dy + 4 * h4), t11 = *reinterpret_cast<const float4*>(t + dy + dx + 4 * h4);
+            v[4 * h4 + 0] = (t00.x * lx0 + t01.x * lx1) * ly0 + (t10.x * lx0 + t11.x * lx1) * ly1;
+            v[4 * h4 + 1] = (t00.y * lx0 + t01.y * lx1) * ly0 + (t10.y * lx0 + t11.y * lx1) * ly1;
+            v[4 * h4 + 2] = (t00.z * lx0 + t01.z * lx1) * ly0 + (t10.z * lx0 + t11.z * lx1) * ly1;
+            v[4 * h4 + 3] = (t00.w * lx0 + t01.w * lx1) * ly0 + (t10.w * lx0 + t11.w * lx1) * ly1;
+        }
+    };
+    bool staged_ready = false;
+    lap_pro(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int kk = ks * 16 + hi * 8;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.stage_folds && !staged_ready && ks * 16 >= p.Cd) {      // (Cd is a multiple of 16 whenever the boxes are staged: launcher)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");                   // everyone's pieces of the boxes
+            staged_ready = true;
+            lap_pro(1);
+        }
         if (kk < p.Cd) {
             const float4 a = *reinterpret_cast<const float4*>(direct + pix * p.Cd + kk), b = *reinterpret_cast<const float4*>(direct + pix * p.Cd + kk + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -184,18 +239,14 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
                         iy = iy > p.Hf[f] - 1 ? p.Hf[f] - 1 : iy;
                         ix = ix > p.Wf[f] - 1 ? p.Wf[f] - 1 : ix;
                         const float ly1 = fy - (float)iy, lx1 = fx - (float)ix;
-                        const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? p.Wf[f] * p.Cf[f] : 0;
-                        const float* t = reinterpret_cast<const float*>(p.fold[f]) + (((size_t)n * p.Hf[f] + iy) * p.Wf[f] + ix) * p.Cf[f] + (kk - seg0);
-                        const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;
-                        // torch's bilinear order: rows blended in x first, then in y (upsample_add's fp32 path, ops.hip)
-#pragma unroll
-                        for (int h4 = 0; h4 < 2; ++h4) {
-                            const float4 t00 = *reinterpret_cast<const float4*>(t + 4 * h4), t01 = *reinterpret_cast<const float4*>(t + dx + 4 * h4);
-                            const float4 t10 = *reinterpret_cast<const float4*>(t + dy + 4 * h4), t11 = *reinterpret_cast<const float4*>(t + dy + dx + 4 * h4);
-                            v[4 * h4 + 0] = (t00.x * lx0 + t01.x * lx1) * ly0 + (t10.x * lx0 + t11.x * lx1) * ly1;
-                            v[4 * h4 + 1] = (t00.y * lx0 + t01.y * lx1) * ly0 + (t10.y * lx0 + t11.y * lx1) * ly1;
-                            v[4 * h4 + 2] = (t00.z * lx0 + t01.z * lx1) * ly0 + (t10.z * lx0 + t11.z * lx1) * ly1;
-                            v[4 * h4 + 3] = (t00.w * lx0 + t01.w * lx1) * ly0 + (t10.w * lx0 + t11.w * lx1) * ly1;
+                        if (p.stage_folds) {
+                            const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? f_bw[f] * p.Cf[f] : 0;
+                            const float* t = reinterpret_cast<const float*>(smem + OFF_W0 + W0_BUF + f_off[f]) + ((iy - f_iy0[f]) * f_bw[f] + (ix - f_ix0[f])) * p.Cf[f] + (kk - seg0);
+                            blend8(t, dx, dy, lx1, ly1, v);
+                        } else {
+                            const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? p.Wf[f] * p.Cf[f] : 0;
+                            const float* t = reinterpret_cast<const float*>(p.fold[f]) + (((size_t)n * p.Hf[f] + iy) * p.Wf[f] + ix) * p.Cf[f] + (kk - seg0);
+                            blend8(t, dx, dy, lx1, ly1, v);
                         }
                     }
                     seg0 += p.Cf[f];
@@ -293,7 +344,11 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
     }
     x3_report(amax, p.range);
     if (tracing && threadIdx.x == 0 && blockIdx.x % 97 == 0)
+    {
         for (int k = 0; k < 6; ++k) p.trace[(size_t)(blockIdx.x / 97) * 8 + k] = tsum[k];
+        p.trace[(size_t)(blockIdx.x / 97) * 8 + 6] = tpro[0];
+        p.trace[(size_t)(blockIdx.x / 97) * 8 + 7] = tpro[1];
+    }
     if constexpr (DEC) {
         // decode-fused epilogue (head32.hip's): per-pixel log-softmax (softmax_px.hpp: the same arithmetic and summation order as the
         // softmax kernels), then the tile's maxima per class over its 32 columns for every row and over its 4 rows for every column
@@ -372,6 +427,18 @@ bool launch_headx3(const HeadParams& p, hipStream_t s) {
         attr_done = true;
     }
     HeadParams q = p;
+    // the folded branches' boxes through LDS (kernel prologue): at most four source rows per tile, both boxes within one stage-1 weight buffer
+    static const int stage = getenv("SNCAL_HEAD_STAGE") ? atoi(getenv("SNCAL_HEAD_STAGE")) : 1;
+    q.stage_folds = stage != 0 && p.Cd % 16 == 0 ? 1 : 0;
+    {
+        int bytes = 0;
+        for (int f = 0; f < p.nfold; ++f) {
+            const int rows = (int)(p.fsy[f] * 3.f) + 3, cols = (int)(p.fsx[f] * 31.f) + 3;
+            if (rows > 4 || p.Cf[f] % 8) q.stage_folds = 0;
+            bytes += (rows * cols * p.Cf[f] * 4 + 1023) / 1024 * 1024;
+        }
+        if (bytes > W0_BUF) q.stage_folds = 0;
+    }
     q.tiles_x = (p.W + 31) / 32;
     q.tiles_y = (p.H + 3) / 4;
     q.tiles_x_magic = q.tiles_x <= 1 ? 0u : 0xFFFFFFFFu / (unsigned)q.tiles_x + 1u;

@@ -5,7 +5,17 @@ tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+export TMPDIR=/tmp
+# the PMC passes first (their own rocprofv3 runs: counters are never combined with traces), so that the bench lines below read this build's
+# roofline.traffic from profiles/pmc_traffic.json
+export PMC_B=64 PMC_DTYPE=fp16x3
+bash tools/pmc_pass.sh ${tag}_x3 FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" 2>&1 | tail -3
+cd $R
+python tools/pmc_traffic.py gpurun_out/${tag}_x3 $tag 64 > gpurun_out/${tag}_x3/traffic.md 2>&1
+python tools/pmc_mfma.py gpurun_out/${tag}_x3 ${tag}_fp16x3 > /dev/null 2>&1
+cp profiles/pmc_traffic.json profiles/${tag}_pmc_hbm_traffic.md profiles/${tag}_fp16x3_pmc_mfma_util.* gpurun_out/${tag}_x3/ 2>/dev/null
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err      # the driver's command
+timeout 900 python tools/noisy_pipeline.py 2048 $O/noisy_pipeline_2048.json > /dev/null 2>&1
 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_c3_bf16.json 2> $O/bench_c3_bf16.err
 python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
 python bench.py --dtype fp8 --no-cpu-baseline > $O/bench_c3_fp8.json 2> $O/bench_c3_fp8.err
@@ -13,7 +23,7 @@ python bench.py --dtype fp8 --size 1080p --batch 64 --no-cpu-baseline > $O/bench
 python bench.py --dtype bf16 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err
 python bench.py --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp16x3.json 2> $O/bench_c5_fp16x3.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof -name "*.csv" -size +2M -delete
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof16 -o trace -- python $R/bench.py --dtype bf16 --no-cpu-baseline --no-parity > $O/bench_c3_bf16_traced.json 2> $O/bench_c3_bf16_traced.err
@@ -30,4 +40,4 @@ python tools/parity_large.py 4096 0.35 > $O/parity_large_4096.log 2>&1
 python tools/latency.py > $O/latency.log 2>&1
 SNCAL_BBX_TRACE=$O/bbx.bin python tools/dev/bbx_trace_run.py > /dev/null 2>&1; python tools/bbx_trace.py $O/bbx.bin > $O/bbx_trace.txt 2>&1; rm -f $O/bbx.bin
 head -c 1500 $O/bench_c3.json; echo; head -c 600 $O/bench_c3_bf16.json; echo; head -c 600 $O/bench_c4.json; echo; head -c 600 $O/bench_c3_fp8.json; echo; head -c 600 $O/bench_c5_fp8.json; echo; head -c 600 $O/bench_c5_bf16.json; echo
-head -8 $O/kernel_stats.csv; tail -12 $O/parity_large_4096.log; cat $O/bbx_trace.txt
+cat $O/noisy_pipeline_2048.json; echo; head -8 $O/kernel_stats.csv; tail -12 $O/parity_large_4096.log; cat $O/bbx_trace.txt

@@ -82,6 +82,18 @@ __device__ __forceinline__ TTMember load_member(int m) {
 #undef TT_CFG_MB
 #undef TT_CFG_NB
 
+// (3, 1): 96 x 4 x 32, split arithmetic only -- SMALL launches (round 5).  Below about two items per team the launch lasts as long as its
+// longest item (twelve stages on the 384-channel branch) while most teams hold three-stage items or nothing: at batch 8, 98 us per
+// grouped launch for 40 us of work per team.  Half the rows per item = twice the items at half a stage's multiplies each; the weight
+// stream per stage is the same (L2 serves it; at these sizes nothing is bandwidth-bound).
+#define TT_CFG_NS c31
+#define TT_CFG_MB 3
+#define TT_CFG_NB 1
+#include "conv_tt_body.inc"
+#undef TT_CFG_NS
+#undef TT_CFG_MB
+#undef TT_CFG_NB
+
 void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s, int cfg) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -89,7 +101,13 @@ void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s, int c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c32::conv_tt_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c32::conv_tt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c23::conv_tt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c31::conv_tt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
+    }
+    if (cfg == 2) {                                    // 96 output channels x 4 rows x 32 columns (split arithmetic, small launches)
+        const size_t lds = (size_t)2 * c31::TEAM_BYTES + 64 + 2 * TT_TABLE_MAX * 4;
+        SNCAL_LAUNCH(c31::conv_tt_kernel<2>, dim3((unsigned)n_wgs), dim3(512), lds, s, p);
+        return;
     }
     if (cfg == 1) {                                    // 64 output channels x 12 rows x 32 columns (bf16x3: the 48-channel branch)
         const size_t lds = (size_t)2 * c23::TEAM_BYTES + 64 + 2 * TT_TABLE_MAX * 4;

@@ -126,7 +126,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
-    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; int lazy = 0; };
+    struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; int lazy = 0; int cfg = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
     // C5: fp8 (OCP e4m3) arithmetic for the wide 3x3 stride-1 convolutions, everything else as the bf16 engine
@@ -1404,10 +1404,24 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     auto it = net.tt_plans.find(key);
     if (it == net.tt_plans.end() || it->second.n_wgs == 0) {       // static per layout: built on the first forward
         sncal_hrnet::TTPlanDev pd;
-        const int rc = tt_build_plan(net, tp.m, n, pd, cfg64 ? 12 : TT_TH, cfg64 ? 64 : TT_COUT);
+        // Small launches of the split-arithmetic engine (round 5): below two 8-row items per team the launch lasts as long as its longest item
+        // while most teams hold short ones or nothing -- the 96 x 4 x 32 tile (conv_tt.hip, c31) halves the items instead
+        int tile_h = cfg64 ? 12 : TT_TH;
+        pd.cfg = cfg64 ? 1 : 0;
+        if (x3 && !cfg64) {
+            const int per_team = getenv("SNCAL_TT_SMALL_ITEMS") ? atoi(getenv("SNCAL_TT_SMALL_ITEMS")) : 2;      // (read per plan: tests run both tiles in one process; 0 = never)
+            long items = 0;
+            for (int i = 0; i < n; ++i)
+                items += (long)((tp.m[i].N * (tp.m[i].H + 1) + TT_TH - 1) / TT_TH) * ((tp.m[i].W + TT_TW - 1) / TT_TW) * ((tp.m[i].cout + TT_COUT - 1) / TT_COUT);
+            int cus = net.n_cus;
+            if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; }
+            if (items < (long)per_team * 2 * cus) { tile_h = 4; pd.cfg = 2; }
+        }
+        const int rc = tt_build_plan(net, tp.m, n, pd, tile_h, cfg64 ? 64 : TT_COUT);
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }
+    const int cfg = it->second.cfg;
     tp.items = it->second.items; tp.xcd_first = it->second.first; tp.lazy = it->second.lazy;
     { const int rc = ensure_tickets(&net, stream); if (rc) return rc; }
     tp.queue = net.d_tickets + 32;
@@ -1421,7 +1435,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     const size_t n_trace = (size_t)it->second.n_wgs * 2 * 256;
     if (trace_file && (trace_cfg64 ? cfg64 : n == 3) && (trace_nth < 0 || trace_seen++ == trace_nth) && hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); tp.trace = d_trace; }
     { static const int abl = getenv("SNCAL_TT_ABLATE") ? atoi(getenv("SNCAL_TT_ABLATE")) : 0; tp.ablate = abl; }
-    launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg64 ? 1 : 0);
+    launch_conv_tt(tp, it->second.n_wgs, fp8 ? 1 : x3 ? 2 : 0, stream, cfg);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
         std::vector<unsigned long long> h(n_trace);
@@ -1453,7 +1467,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
     }
     if (net.profiling) {
         for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, nullptr, i > 0);
-        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,12x32x64>" : x3 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
+        net.last_kernel = fp8 ? "conv_tt<fp8,k3,s1,8x32x96>" : cfg64 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,12x32x64>" : cfg == 2 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,4x32x96>" : x3 ? "conv_tt<" SNCAL_X3_NAME ",k3,s1,8x32x96>" : "conv_tt<bf16,k3,s1,8x32x96>";
         static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;      // tuning aid: one profile row per launch kind
         if (detail) net.last_kernel += fmt("@%d members%s%s%s", n, tp.m[0].res ? "+res" : "", tp.m[0].out ? "+f32" : "", tp.m[0].out8 ? "+twin" : "");
     }

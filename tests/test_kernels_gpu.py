@@ -543,14 +543,17 @@ def test_every_launch_of_the_fp32_engine_w18(sncal, cuda):
     assert any(k.startswith('conv<f32') for k in stats)
 
 
-def test_every_launch_of_the_fp16x3_engine_w48_540p(sncal, cuda):
+@pytest.mark.parametrize('small_items', ['2', '0'])
+def test_every_launch_of_the_fp16x3_engine_w48_540p(sncal, cuda, monkeypatch, small_items):
     """The fp32-class engine: fp32 tensors everywhere, the 3x3 stride-1 convolutions of stages 2-4 (wide branches and the 48-channel
     branch as fused BasicBlocks, bblockx3.hip) in split-fp16 arithmetic -- each against torch fp32 on the
     split twin it reads (hi + lo; written by the producing convolution's epilogue or by split_f32_kernel), its fp32 output and the
-    split twin it hands on."""
+    split twin it hands on.  Twice: three frames are a SMALL launch and take the two-team kernel's 96 x 4 x 32 tile by default
+    (SNCAL_TT_SMALL_ITEMS = 2 items per team, hrnet.cpp run_conv_tt); 0 forces the 96 x 8 x 32 tile of the large batches."""
+    monkeypatch.setenv('SNCAL_TT_SMALL_ITEMS', small_items)
     sd = _weights('hrnet_w48')
-    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'fp16x3', tag='w48 540p fp16x3')
-    _report(stats, 'fp16x3_w48_540p')
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', sd, _frames(3, 540, 960, 18, cuda), 'fp16x3', tag='w48 540p fp16x3 small tile ' + small_items)
+    _report(stats, 'fp16x3_w48_540p' + ('' if small_items == '2' else '_tile8'))
     k, kb = 'conv_tt<fp16x3,k3,s1,8x32x96>', 'bblockx3_fused'   # 144 wide convolutions + 32 fused 48-channel blocks, each checked on its fp32 output, its twin, or both
     n = lambda key: stats.get(key, {'ops': 0})['ops']
     assert n(k) >= 12 and n(k + ' split out') >= 120                                         # (fp32 outputs: module ends only)

@@ -1564,7 +1564,13 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         sp.tiles_per_xcd = (sp.tiles + 7) / 8;
         launch_conv_shared_s2_x3(sp, 8u * sp.tiles_per_xcd * ipt, lds_s, stream);
         SNCAL_CHECK_LAUNCH();
-        if (net.profiling) for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, vs[i], i > 0);
+        if (net.profiling) {
+            for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, vs[i], i > 0);
+            const Tensor& ti = net.tensors[ops[0].in];
+            net.last_bytes -= (double)(n - 1) * sb * ti.H * ti.W * ti.C * net.esize;      // the members' common input counts once
+            static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;
+            if (!detail) net.last_kernel = "conv_shared_s2<" SNCAL_X3_NAME ",k3,NI2,G3>";     // (its own row: not the first member's variant)
+        }
         *done = true;
         return SNCAL_OK;
     }

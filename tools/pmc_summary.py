@@ -7,9 +7,11 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         m = re.search(r'conv_(?:group_)?kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
-        if 'conv_tt_kernel' in k:
+        if 'conv_shared_s2_kernel' in k:
+            k, m = 'conv_shared_s2<fp16x3,k3,NI2,G3>', None
+        elif 'conv_tt_kernel' in k:
             mode = 'fp8' if ('ILb1' in k or '<true>' in k or 'ILi1E' in k or 'kernel<1>' in k) else 'fp16x3' if ('ILi2E' in k or 'kernel<2>' in k) else 'bf16'
-            k = 'conv_tt<%s,k3,s1,%s>' % (mode, '12x32x64' if 'c23' in k else '8x32x96')
+            k = 'conv_tt<%s,k3,s1,%s>' % (mode, '12x32x64' if 'c23' in k else '4x32x96' if 'c31' in k else '8x32x96')
         elif m:
             ty = {'DF16b': 'bf16', 'NS_4x3_tE': 'fp16x3'}.get(m.group(1), 'f32')
             k = 'conv<%s,k%s,s%s,NI%s,MI%s,G%s>' % ((ty,) + m.groups()[1:])

@@ -489,7 +489,9 @@ int launch_bblockx3(const BBlockX3Params& p0, hipStream_t s) {
     BBlockX3Params p = p0;
     // one launch addresses its tensors with 32-bit buffer offsets: more frames than fit go in several launches
     const size_t img = (size_t)p.H * p.W * (size_t)(p.out && p.out_cstride * 4 > 192 ? p.out_cstride * 4 : 192);
-    const size_t n_max = img ? (size_t)0xf0000000u / img : 0;
+    const char* lim_env = getenv("SNCAL_BBX_MAX_BYTES");             // (test hook: a small limit sends a small batch down the several-launches path)
+    const size_t lim = lim_env ? (size_t)atoll(lim_env) : (size_t)0xf0000000u;
+    const size_t n_max = img ? lim / img : 0;
     if (n_max == 0 || (size_t)(p.H + 1) * (p.H + 1) * (n_max < (size_t)p.N ? n_max : (size_t)p.N) >= ((size_t)1 << 32)) {
         set_error("launch_bblockx3: image too large for 32-bit offsets");
         return SNCAL_ERR_ARG;

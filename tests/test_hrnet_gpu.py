@@ -326,3 +326,19 @@ def test_ticket_dealt_kernels_give_the_same_bytes_beside_a_busy_side_stream(snca
         heat, kp = net.forward(x, want_heat=True, decode_size=(540, 960))
         torch.cuda.synchronize()
         assert torch.equal(heat, heat0) and torch.equal(kp, kp0), rep
+
+
+def test_fused_block_in_several_launches_gives_the_same_bytes(sncal, cuda, monkeypatch):
+    """bblockx3 addresses one launch's tensors with 32-bit buffer offsets; a sub-batch whose tensors exceed them goes out as several launches
+    over frame ranges (launch_bblockx3).  No shipped configuration reaches the limit (64 frames of 1920x1080 are 1.6 GB per tensor), so the
+    path is driven here through the launcher's test hook: with the limit at three frames' worth of bytes a 7-frame forward runs every fused
+    block as 3 + 3 + 1 frames, and must return the one-launch result byte for byte (tiles of the stacked frames differ between the two)."""
+    cfg = hr.load_config('hrnet_w48')
+    net = sncal.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=cuda)
+    net.load_state_dict(hr.seeded_state_dict(cfg, 31, 4.0))
+    x = hr.seeded_input(7, 270, 480, 32).to(cuda)
+    heat0, kp0 = net.forward(x, want_heat=True, decode_size=(540, 960))
+    heat0, kp0 = heat0.clone(), kp0.clone()
+    monkeypatch.setenv('SNCAL_BBX_MAX_BYTES', str(3 * 68 * 120 * 192 + 1000))      # (the 48-channel branch of a 270x480 input: 68 x 120 x 192 B per frame)
+    heat, kp = net.forward(x, want_heat=True, decode_size=(540, 960))
+    assert torch.equal(heat, heat0) and torch.equal(kp, kp0)

@@ -213,6 +213,23 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
             v[4 * h4 + 3] = (t00.w * lx0 + t01.w * lx1) * ly0 + (t10.w * lx0 + t11.w * lx1) * ly1;
         }
     };
+    // per fold and lane, once: LDS float index of the lane's first tap, tap distances, blend weights (the staged path)
+    int f_t0[HEAD_MAX_FOLD], f_dx[HEAD_MAX_FOLD], f_dy[HEAD_MAX_FOLD];
+    float f_lx[HEAD_MAX_FOLD], f_ly[HEAD_MAX_FOLD];
+#pragma unroll
+    for (int f = 0; f < HEAD_MAX_FOLD; ++f) {
+        f_t0[f] = f_dx[f] = f_dy[f] = 0; f_lx[f] = f_ly[f] = 0.f;
+        if (p.stage_folds && f < p.nfold) {
+            const float fy = p.fsy[f] * (float)yc, fx = p.fsx[f] * (float)xc;     // align_corners=True
+            int iy = (int)fy, ix = (int)fx;
+            iy = iy > p.Hf[f] - 1 ? p.Hf[f] - 1 : iy;
+            ix = ix > p.Wf[f] - 1 ? p.Wf[f] - 1 : ix;
+            f_ly[f] = fy - (float)iy; f_lx[f] = fx - (float)ix;
+            f_dx[f] = ix < p.Wf[f] - 1 ? p.Cf[f] : 0;
+            f_dy[f] = iy < p.Hf[f] - 1 ? f_bw[f] * p.Cf[f] : 0;
+            f_t0[f] = (OFF_W0 + W0_BUF + f_off[f]) / 4 + ((iy - f_iy0[f]) * f_bw[f] + (ix - f_ix0[f])) * p.Cf[f];
+        }
+    }
     bool staged_ready = false;
     lap_pro(0);
 #pragma unroll
@@ -234,16 +251,14 @@ __global__ __launch_bounds__(256, 2) void headx3_kernel(const HeadParams p) {
             for (int f = 0; f < HEAD_MAX_FOLD; ++f) {
                 if (f < p.nfold) {
                     if (kk >= seg0 && kk < seg0 + p.Cf[f]) {
-                        const float fy = p.fsy[f] * (float)yc, fx = p.fsx[f] * (float)xc;     // align_corners=True
-                        int iy = (int)fy, ix = (int)fx;
-                        iy = iy > p.Hf[f] - 1 ? p.Hf[f] - 1 : iy;
-                        ix = ix > p.Wf[f] - 1 ? p.Wf[f] - 1 : ix;
-                        const float ly1 = fy - (float)iy, lx1 = fx - (float)ix;
                         if (p.stage_folds) {
-                            const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? f_bw[f] * p.Cf[f] : 0;
-                            const float* t = reinterpret_cast<const float*>(smem + OFF_W0 + W0_BUF + f_off[f]) + ((iy - f_iy0[f]) * f_bw[f] + (ix - f_ix0[f])) * p.Cf[f] + (kk - seg0);
-                            blend8(t, dx, dy, lx1, ly1, v);
+                            blend8(reinterpret_cast<const float*>(smem) + f_t0[f] + (kk - seg0), f_dx[f], f_dy[f], f_lx[f], f_ly[f], v);
                         } else {
+                            const float fy = p.fsy[f] * (float)yc, fx = p.fsx[f] * (float)xc;     // align_corners=True
+                            int iy = (int)fy, ix = (int)fx;
+                            iy = iy > p.Hf[f] - 1 ? p.Hf[f] - 1 : iy;
+                            ix = ix > p.Wf[f] - 1 ? p.Wf[f] - 1 : ix;
+                            const float ly1 = fy - (float)iy, lx1 = fx - (float)ix;
                             const int dx = ix < p.Wf[f] - 1 ? p.Cf[f] : 0, dy = iy < p.Hf[f] - 1 ? p.Wf[f] * p.Cf[f] : 0;
                             const float* t = reinterpret_cast<const float*>(p.fold[f]) + (((size_t)n * p.Hf[f] + iy) * p.Wf[f] + ix) * p.Cf[f] + (kk - seg0);
                             blend8(t, dx, dy, lx1, ly1, v);

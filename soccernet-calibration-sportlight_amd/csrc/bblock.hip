@@ -44,7 +44,7 @@ constexpr int BB_LDS = 4 * BB_WBYTES + BB_XBYTES + BB_MIDBYTES;
 constexpr int BB_PF = 1;                         // operand prefetch distance in k-steps
 constexpr int BB_NW = 8;                         // waves per workgroup: two per SIMD
 constexpr int BB_J1 = (BB_MH + BB_NW - 1) / BB_NW, BB_J2 = BB_TH / BB_NW;      // pixel fragments (tile rows) per wave: conv1 (at most), conv2
-static_assert(BB_TH % BB_NW == 0 && BB_J1 == BB_J2 + 1 && BB_LDS <= 160 * 1024, "tile rows split evenly over the waves; one workgroup per CU");
+static_assert(BB_TH % BB_NW == 0 && BB_J1 == BB_J2 + 1 && BB_LDS + 16 <= 160 * 1024, "tile rows split evenly over the waves; one workgroup per CU");
 
 // PERSISTENT (round 2): one workgroup of four waves per CU walks a contiguous range of tiles with the block's whole weight set
 // (conv1 + conv2, 4 x 21 KB) RESIDENT in LDS.  The round-1 kernel launched one workgroup per tile and staged those 84 KB for
@@ -76,10 +76,18 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
 
     // tiles of this workgroup: the launch's tiles are cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8);
     // the workgroups of an XCD take consecutive tiles of its range, so neighbouring halos meet in one L2
-    const int per_xcd = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, wx = (int)blockIdx.x >> 3;
+    // Round 5: IN ORDER from a ticket counter of the XCD (p.ticket[xcd]) instead of a fixed stride -- a workgroup whose CU another stream's
+    // work holds (the camera solves of the previous batch, CU-masked to one CU per XCD) takes fewer tiles instead of walking its whole
+    // share after everybody else has left (the launch then lasted twice as long: 276 us on average against 200 beside the solves).
+    // Thread 0 draws the ticket of the NEXT tile at the top of a tile and publishes it behind conv1 (the atomic's round trip rides under
+    // the multiplies); everybody reads it behind the mid barrier, where the next halo is requested.
+    const int xcd = (int)blockIdx.x & 7;
     const int n_tiles = p.N * p.tiles_y * p.tiles_x;
     const int t_lo = (int)((long)n_tiles * xcd / 8), t_hi = (int)((long)n_tiles * (xcd + 1) / 8);
-    int t = t_lo + wx;
+    unsigned* const s_next = reinterpret_cast<unsigned*>(smem + BB_LDS);        // [2]: the next tile, by parity of the tile count
+    if (tid == 0) s_next[0] = (unsigned)t_lo + atomicAdd(p.ticket + xcd, 1u);
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane((int)s_next[0]);
 
     const size_t img_bytes = (size_t)p.H * p.W * 48 * 2;
     const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, 2 * BB_WBYTES, 0x00020000);
@@ -123,7 +131,6 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
     };
     // tile coordinates: decoded once (scalar divisions), then advanced by the stride of the walk
     int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tn = t / (p.tiles_x * p.tiles_y);
-    const int step_x = per_xcd % p.tiles_x, step_y = per_xcd / p.tiles_x;      // per_xcd tiles further = step_y rows and step_x columns
     if (t < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW, wave, BB_NW);
 
     // fragment offsets of k-step s within a 24-channel chunk: k-group kg = 4s + g -> (tap, cg); same order as pack_layer
@@ -219,16 +226,16 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
     auto lap = [&](int k) { if (tracing) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[k] += now - tprev; tprev = now; } };
 
     auto nohook = [](int) {};
-    for (; t < t_hi; t += per_xcd) {
+    int t_next = t_hi;
+    for (unsigned ti = 0; t < t_hi; ++ti, t = t_next) {
         if (tracing) tprev = __builtin_amdgcn_s_memtime();
         const int n = tn, oy0 = ty * BB_TH, ox0 = tx * BB_TW;
-        tx += step_x; ty += step_y;                           // the next tile of this workgroup
-        if (tx >= p.tiles_x) { tx -= p.tiles_x; ++ty; }
-        while (ty >= p.tiles_y) { ty -= p.tiles_y; ++tn; }
         init_acc(bias1);
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0), as a builtin so that hipcc's wait-count pass sees it: my pieces
         asm volatile("" ::: "memory");                        // of this tile's x halo (first tile: and of the weights) have landed
         asm volatile("s_barrier" ::: "memory");               // ... then everyone's, and everyone is past the old mid
+        unsigned tk_next = 0;
+        if (tid == 0) tk_next = atomicAdd(p.ticket + xcd, 1u);                // (in flight under conv1)
         lap(0);
         // the previous tile's outputs are stored between conv1's two K-chunks: behind the opening wait (whose vmcnt(0) they would
         // otherwise prolong) and while the SIMD's other wave keeps the matrix pipe busy
@@ -269,20 +276,23 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
             }
         }
         init_acc(bias2);
+        if (tid == 0) s_next[(ti + 1u) & 1u] = (unsigned)t_lo + tk_next;      // (slot of tile ti + 1: last read behind tile ti - 1's mid barrier)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my mid rows are written, my residual is in registers
         lap(2);
         asm volatile("s_barrier" ::: "memory");               // ... everyone's: mid is complete, nobody reads this x halo any more
+        t_next = __builtin_amdgcn_readfirstlane((int)s_next[(ti + 1u) & 1u]);
+        tx = t_next % p.tiles_x; ty = (t_next / p.tiles_x) % p.tiles_y; tn = t_next / (p.tiles_x * p.tiles_y);
         lap(6);
         // The next tile's halo lands under conv2.  The four YOUNGER waves (4..7) request it, ten pieces each, before their conv2: the
         // matrix pipe favours the older wave of a SIMD, so waves 0..3 go straight into conv2 (per-wave phase trace, tools/bb_trace.py:
         // requested by all eight waves it cost ~0.9k clk per tile between the barrier and the first conv2 MFMA; spread between the
         // younger waves' k-steps the last pieces were requested too late and the next tile waited for them).
-        if (!(p.dbg & 2) && t + per_xcd < t_hi && wave >= BB_NW / 2) issue_x(tn, ty * BB_TH, tx * BB_TW, wave - BB_NW / 2, BB_NW / 2);
+        if (!(p.dbg & 2) && t_next < t_hi && wave >= BB_NW / 2) issue_x(tn, ty * BB_TH, tx * BB_TW, wave - BB_NW / 2, BB_NW / 2);
         lap(7);
         mma_chunk(s_w + 2 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 0, std::integral_constant<int, BB_J2>{}, nohook);
         mma_chunk(s_w + 3 * BB_WBYTES, s_mid, boff2, BB_MW * BB_PS, 1, std::integral_constant<int, BB_J2>{}, nohook);
 
-        if ((p.dbg & 2) && t + per_xcd < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW, wave, BB_NW);
+        if ((p.dbg & 2) && t_next < t_hi) issue_x(tn, ty * BB_TH, tx * BB_TW, wave, BB_NW);
         lap(3);
         // epilogue: + x, ReLU -> packed bf16 in registers (4 channels = 8 bytes per lane and fragment); stored by `flush`
         rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
@@ -300,6 +310,12 @@ __global__ __launch_bounds__(64 * BB_NW, 1) void bblock48_kernel(const BBlockPar
         tsum[5] += 1;
     }
     if (pending) flush();
+    // every workgroup holds exactly one failing ticket when it leaves; the last one re-arms the counters for the next launch on this stream
+    if (tid == 0 && atomicAdd(p.ticket + 8, 1u) == gridDim.x - 1u) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p.ticket[i] = 0u;
+        __threadfence();
+    }
     if (tracing && lane == 0)
         for (int k = 0; k < 8; ++k) p.trace[((size_t)blockIdx.x * BB_NW + wave) * 8 + k] = tsum[k];
 }
@@ -321,7 +337,8 @@ int launch_bblock48(const BBlockParams& p0, hipStream_t s) {
     }
     static const char* trace_file = getenv("SNCAL_BB_TRACE");
     if (trace_file && hipMalloc(&p.trace, (size_t)n_wgs * BB_NW * 64) == hipSuccess) (void)hipMemsetAsync(p.trace, 0, (size_t)n_wgs * BB_NW * 64, s);
-    SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)n_wgs), dim3(64 * BB_NW), (size_t)BB_LDS, s, p);
+    if (!p.ticket) { set_error("launch_bblock48: no ticket words"); return SNCAL_ERR_ARG; }
+    SNCAL_LAUNCH(bblock48_kernel, dim3((unsigned)n_wgs), dim3(64 * BB_NW), (size_t)BB_LDS + 16, s, p);
     SNCAL_CHECK_LAUNCH();
     if (p.trace) {      // every launch overwrites the dump: the file holds the last fused block of the run
         std::vector<unsigned long long> h((size_t)n_wgs * BB_NW * 8);

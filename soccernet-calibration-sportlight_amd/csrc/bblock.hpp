@@ -15,6 +15,7 @@ struct BBlockParams {
     int tiles_x, tiles_y;   // filled by the launcher
     int dbg;                // tuning aid (SNCAL_BB_DBG): 1 = drop the output stores, 2 = request the next halo after conv2 (timing only)
     unsigned long long* trace;   // tuning aid (SNCAL_BB_TRACE=<file>): 16 s_memtime stamps per workgroup, or null
+    unsigned* ticket;       // nine zeroed device words owned by the caller's stream: tile tickets per XCD [0..8), workgroups that ran dry [8] (re-armed by the kernel)
 };
 
 int launch_bblock48(const BBlockParams& p, hipStream_t s);

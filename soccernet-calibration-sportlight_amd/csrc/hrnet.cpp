@@ -2213,6 +2213,9 @@ static int forward_impl(sncal_hrnet* net, const float* d_x, const unsigned char*
                         bp.w1 = net->layers[op.conv].d_w; bp.b1 = net->layers[op.conv].d_bias;
                         bp.w2 = net->layers[op2->conv].d_w; bp.b2 = net->layers[op2->conv].d_bias;
                         bp.N = sb; bp.H = ti.H; bp.W = ti.W; bp.tiles_x = bp.tiles_y = 0; bp.trace = nullptr;
+                        rc = ensure_tickets(net, stream);
+                        if (rc) return rc;
+                        bp.ticket = net->d_tickets + 48;
                         rc = launch_bblock48(bp, stream);
                         if (net->profiling) {
                             net->last_kernel = "bblock48_fused";

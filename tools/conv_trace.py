@@ -1,7 +1,7 @@
 """Dev helper: summarise a SNCAL_CONV_TRACE dump (16 x u64 per workgroup: hwid, start, [wait_done, mfma_done] x chunks, end)."""
 import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)
-nch = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+nch = min(int(sys.argv[2]) if len(sys.argv) > 2 else 3, 6)      # (the dump holds 16 stamps per workgroup: at most six chunks' pairs)
 a = a[a[:, 1] > 0]
 t0 = a[:, 1].min()
 T = (a[:, 1:] - t0).astype(np.int64)          # column k = stamp k+1

@@ -593,6 +593,12 @@ void choose_packing(sncal_hrnet& net, ConvLayer& L) {
           if (force_g && L.k == 3 && L.stride == 1 && L.cin_phys >= 96 && V.g != force_g) continue;
           static const int force_g48 = getenv("SNCAL_FORCE_G48") ? atoi(getenv("SNCAL_FORCE_G48")) : 0;
           if (force_g48 && L.k == 3 && L.stride == 1 && L.cin_phys == 48 && L.cout == 48 && V.g != force_g48) continue; }
+        {   // tuning aid: SNCAL_FORCE_PACK="k,stride,cin,cout,mi,g" pins the packing of the layers of that shape (cout 0 = any)
+            static const char* fp = getenv("SNCAL_FORCE_PACK");
+            int fk, fs, fci, fco, fmi, fg;
+            if (fp && sscanf(fp, "%d,%d,%d,%d,%d,%d", &fk, &fs, &fci, &fco, &fmi, &fg) == 6 && L.k == fk && L.stride == fs && L.cin_phys == fci &&
+                (fco == 0 || L.cout == fco) && (V.mi != fmi || V.g != fg)) continue;
+        }
         const int chunks = (L.cin_phys + V.g * ge - 1) / (V.g * ge);
         const int nks = conv_nks(V.ks, V.g);
         const double k_eff = (double)(L.k * L.k * L.cin_phys / ge) / (double)(chunks * nks * 4);

@@ -32,8 +32,9 @@ ride on the line as `bf16` and `fp32`.
 Parity of the benchmarked path rides on the same line (`parity`, computed OUTSIDE the timed region on the same frames):
 the benchmarked engine against this build's exact-fp32 engine (the one pinned to the reference goldens by
 tests/test_hrnet_gpu.py): keypoint-index agreement, and the relative difference of the solved cameras' reprojection
-error; plus the fp32 engine's own frames/s.  With N > 1 every rank processes its own 64 frames (weak scaling, frames
-are independent) and one RCCL all_gather of the per-frame records closes the step.  Rank 0 prints ONE JSON line.
+error; plus the fp32 engine's own frames/s.  With N > 1 every rank processes its own 64 frames per step (weak scaling, frames
+are independent); the per-frame records stay on the rank and ONE RCCL all_gather of all K steps' records closes the timed
+region (north_star: "a single RCCL gather over xGMI at the end").  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -41,11 +42,10 @@ import os
 import sys
 import time
 
-# The step uses three streams (network, solves, RCCL's internal one).  HIP multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that land on one queue run in submission order, and
-# measured on MI355X the RCCL stream then shares a queue with the network stream: the all_gather's wait for the
-# solves stalls the next step's convolutions, 43.1 -> 54.5 ms per step.  With 8 queues the collective costs nothing.
-# Must be set before the HIP runtime initialises.
+# The step uses the network's stream and three solve streams (+ RCCL's internal one, active only for the one gather after the
+# last step).  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that land on one queue run
+# in submission order (measured in round 2 with a per-step gather: RCCL's stream shared a queue with the network stream and the
+# step went 43.1 -> 54.5 ms).  With 8 queues no two of them alias.  Must be set before the HIP runtime initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np  # noqa: E402
@@ -403,17 +403,21 @@ def self_launch(args):
 
 
 def dry_dist(rank, world):
-    """--dry-dist: the multi-rank skeleton of a step on CPU (gloo) -- rendezvous, the path's one collective on rank-coded records
-    (sncal_amd.dist, the same functions the pipeline calls), barrier, max-over-ranks -- without any GPU work."""
+    """--dry-dist: the multi-rank skeleton of a run on CPU (gloo) -- rendezvous, two steps of rank-coded records logged on the rank,
+    the path's one collective at the end (sncal_amd.dist.RecordLog, the object the pipeline uses), barrier, max-over-ranks -- without
+    any GPU work."""
     import torch.distributed as dist
-    from sncal_amd.dist import gather_records, pack_records
+    from sncal_amd.dist import RecordLog, pack_records
     if world > 1:
         dist.init_process_group('gloo')
-    per = 4
-    kp = torch.full((per, 57, 3), float(rank), dtype=torch.float32)
-    rec = torch.full((per, 136), rank, dtype=torch.uint8)
+    per = 2
+    log = RecordLog()
     t0 = time.perf_counter()
-    allrec = gather_records(pack_records(kp, rec))
+    for step in range(2):
+        kp = torch.full((per, 57, 3), float(rank), dtype=torch.float32)
+        rec = torch.full((per, 136), rank, dtype=torch.uint8)
+        log.add(pack_records(kp, rec))
+    allrec = log.gather()
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -526,8 +530,8 @@ def main():
             step_marks[-1].record()
         # forward + decode on the main stream; the solve of THESE keypoints on the pipeline's side stream (it overlaps the
         # next step's convolutions); every solve is complete before the closing fence of the timed region.
-        # multi-GPU: the single collective of the path (per-frame records to every rank, RCCL over xGMI) rides on the
-        # side stream behind the solve
+        # multi-GPU: the step only LOGS its packed records on the rank (pipeline.log); the single collective of the path
+        # (all steps' records to every rank, RCCL over xGMI) is issued once, behind the last step (close_run)
         for i in range(L):
             if diag_nosolve:                             # diagnosis only: network + decode, no solves (not a valid bench line)
                 nets[i].forward(xs[i], want_heat=False, decode_size=(540, 960))
@@ -543,9 +547,13 @@ def main():
         for i in range(L):
             if lane_streams[i] is None:
                 pipes[i].join()
+                if use_dist and len(pipes[i].log):
+                    last['gathered', i] = (pipes[i].log.local(), pipes[i].gather_all())     # the path's ONE collective: every step's records
             else:
                 with torch.cuda.stream(lane_streams[i]):
                     pipes[i].join()
+                    if use_dist and len(pipes[i].log):
+                        last['gathered', i] = (pipes[i].log.local(), pipes[i].gather_all())
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -585,10 +593,10 @@ def main():
                 m[k] += q[k]
         n.set_profiling(False)
     prof = list(merged.values())
-    if args.dump_gather and use_dist and rank == 0:      # the path's one collective, as it ran in the last timed step
+    if args.dump_gather and use_dist and rank == 0:      # the path's one collective, as it closed the timed region: K steps' records at once
         from sncal_amd.dist import pack_records
-        np.savez(args.dump_gather, local=pack_records(last[0][0], last[0][1]).cpu().numpy(), gathered=last[0][-1].cpu().numpy(),
-                 world=world, rank=rank)
+        np.savez(args.dump_gather, local=last['gathered', 0][0].cpu().numpy(), gathered=last['gathered', 0][1].cpu().numpy(),
+                 last_step=pack_records(last[0][0], last[0][1]).cpu().numpy(), world=world, rank=rank, steps=args.steps)
     if diag:                                             # diagnosis runs print the step time only
         print('diag', diag, round(dt / args.steps * 1e3, 3), 'ms/step', 'steady', round(steady_ms, 3) if steady_ms else None)
         return
@@ -682,7 +690,7 @@ def main():
             'data': 'synthetic (noise frames stamped with per-keypoint codes at the pitch template\'s projections through sampled cameras; '
                     'random-init HRNet-W48 with the deep signal path of synth.deep_state_dict: the codes travel through every backbone tensor -> peaked heatmaps; see bench.py docstring)',
             'config': {'workload': wl, 'frames_per_gpu': B, 'lanes': L,
-                       'parallelism': f'frames sharded over {world} GPU(s), one all_gather per step' if world > 1 else 'single GPU',
+                       'parallelism': f'frames sharded over {world} GPU(s), records stay on the rank, ONE all_gather of all {args.steps} steps\' records closes the timed region' if world > 1 else 'single GPU',
                        'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}', 'solver': solver_note,
                        'decoded_within_8px_of_stamp': round(hit, 4), 'visible_keypoint_conf_median': round(float(np.median(conf_vis)), 4),
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * flop_frame / 1e12, 1),

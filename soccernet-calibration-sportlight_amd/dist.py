@@ -1,6 +1,7 @@
 """Frame sharding across the GPUs of one node: frames are independent through the whole path, so
-each rank owns a contiguous block of frames, weights are replicated, and the ONLY exchange is one all_gather
-of the per-frame result records (keypoints + camera records, < 1 KB per frame) at the end of a pass.
+each rank owns a contiguous block of frames, weights are replicated, and the ONLY exchange is ONE all_gather
+of the per-frame result records (keypoints + camera records, < 1 KB per frame) after the rank's LAST batch
+(`RecordLog`: the records of every batch stay on the rank until then; north_star: "a single RCCL gather over xGMI at the end").
 `backend='nccl'` is RCCL over xGMI on ROCm; the same code runs on gloo for CPU tests."""
 import torch
 import torch.distributed as dist
@@ -37,3 +38,35 @@ def gather_records(local: torch.Tensor, counts=None) -> torch.Tensor:
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+class RecordLog:
+    """The per-rank side of the path's single collective: packed records of every batch a rank has processed stay on the rank
+    (`add`), and `gather` issues ONE all_gather_into_tensor for all of them after the last batch.  No collective, hence no RCCL
+    stream, is active while batches are in flight: a per-batch gather sat on the solve stream behind the solve (every step's
+    collective waited for the slowest rank's slowest Levenberg-Marquardt fit) and took one of the four hardware queues the
+    network and the solve streams need (pipeline.py).  Ranks may hold different frame counts (ragged shards: `counts`)."""
+
+    def __init__(self):
+        self.parts = []
+
+    def add(self, packed: torch.Tensor):
+        self.parts.append(packed)
+
+    def __len__(self):
+        return sum(p.shape[0] for p in self.parts)
+
+    def local(self) -> torch.Tensor:
+        """This rank's records in submission order, (frames of the rank, bytes) uint8."""
+        if not self.parts:
+            raise ValueError('RecordLog.local(): no batch was logged')
+        if len(self.parts) > 1:
+            self.parts = [torch.cat(self.parts, dim=0)]
+        return self.parts[0]
+
+    def gather(self, counts=None) -> torch.Tensor:
+        """The one collective: (all frames of all ranks in frame order, bytes).  `counts` = frames per rank when they differ.
+        The caller orders the current stream behind the producers of the logged tensors first (CalibrationPipeline.gather_all)."""
+        out = gather_records(self.local(), counts)
+        self.parts = []
+        return out

@@ -39,11 +39,12 @@ from . import _lib
 # Solve streams per device.  THREE, not more: the network's stream + three solve streams are four hardware queues, and a fifth ACTIVE
 # queue costs the network 6.6 ms per 88 ms step even when the solves are short (measured at the 200-iteration cap: 1, 2, 3 solve
 # streams 87.9 ms per step, 4 streams 94.5, 4 streams squeezed onto GPU_MAX_HW_QUEUES=4 queues 88.1 -- the compute pipes serve four
-# queues side by side and time-slice beyond that).  With the multi-GPU gather RCCL's own stream is one of the four: two solve streams.
+# queues side by side and time-slice beyond that).  Multi-GPU runs keep all three: the path's one collective is issued ONCE, after the
+# last batch (`gather_all`), so RCCL's stream is idle while batches are in flight (rounds 2-5 gathered per step on the solve stream and
+# gave RCCL the fourth queue: two solve streams, and every step's collective behind the slowest rank's slowest fit).
 SOLVE_STREAMS = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS', '3')))
-SOLVE_STREAMS_DIST = max(1, int(os.environ.get('SNCAL_SOLVE_STREAMS_DIST', '2')))
 SOLVE_CUS_PER_XCD = int(os.environ.get('SNCAL_SOLVE_CUS_PER_XCD', '1'))      # 0 = unmasked solve streams (round-4 behaviour)
-_POOLS = {}      # (device index, masked) -> [solve streams, next]: one pool per device and kind (lanes share it: hardware queues are few)
+_POOLS = {}      # (device index, masked) -> [solve streams, next, masked]: one pool per device and kind (lanes share it: hardware queues are few)
 _OWN = {}        # device index -> a non-blocking stream for callers that have none (CalibrationPipeline.stream)
 
 
@@ -53,23 +54,39 @@ def _device_index(device):
 
 
 def _n_streams():
-    import torch.distributed as dist
-    return SOLVE_STREAMS_DIST if dist.is_available() and dist.is_initialized() else SOLVE_STREAMS
+    return SOLVE_STREAMS
+
+
+_MASK_REFUSED = set()     # device indices whose runtime refused a CU-masked stream (warned once; plain solve streams from then on)
 
 
 def _solve_pool(device, masked):
-    key = (_device_index(device), bool(masked))
+    """-> ([streams], next, masked): the device's pool of solve streams.  A device that refuses the CU mask (a CU count that is not a
+    multiple of 8, a runtime without hipExtStreamCreateWithCUMask) gets the unmasked pool with a warning instead of an error: the
+    solves then pay the scattered-CU price of the module docstring, the results are the same."""
+    idx = _device_index(device)
+    masked = bool(masked) and idx not in _MASK_REFUSED
+    key = (idx, masked)
     if key not in _POOLS:
         streams = []
-        with torch.cuda.device(key[0]):
+        with torch.cuda.device(idx):
             for _ in range(_n_streams()):
                 if masked:
                     h = _lib.vp()
-                    _lib.check(_lib.lib().sncal_stream_create_cu_mask(SOLVE_CUS_PER_XCD, h), 'sncal_stream_create_cu_mask')
-                    streams.append(torch.cuda.ExternalStream(h.value, device=torch.device('cuda', key[0])))
+                    st = _lib.lib().sncal_stream_create_cu_mask(SOLVE_CUS_PER_XCD, h)
+                    if st != 0:
+                        import warnings
+                        why = _lib.lib().sncal_last_error().decode(errors='replace')
+                        warnings.warn(f'cuda:{idx}: CU-masked solve streams unavailable ({why}); '
+                                      'using plain solve streams (solver wavefronts may land on any CU)')
+                        for q in streams:
+                            _lib.lib().sncal_stream_destroy(q.cuda_stream)
+                        _MASK_REFUSED.add(idx)
+                        return _solve_pool(device, False)
+                    streams.append(torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx)))
                 else:
-                    streams.append(torch.cuda.Stream(device=key[0]))
-        _POOLS[key] = [streams, 0]
+                    streams.append(torch.cuda.Stream(device=idx))
+        _POOLS[key] = [streams, 0, masked]
     return _POOLS[key]
 
 
@@ -89,6 +106,9 @@ class CalibrationPipeline:
         self.device = net.device
         self.max_in_flight = 2 * _n_streams()
         self._pending = []
+        self._unjoined = []                 # completion events of the batches logged for gather_all()
+        from .dist import RecordLog
+        self.log = RecordLog()              # submit(gather=True): this rank's packed records, batch after batch
         self.last_done = None
         self.masked = False                 # kind of solve stream the last submit() used
 
@@ -104,7 +124,7 @@ class CalibrationPipeline:
 
     def _next_solve_stream(self, masked):
         pool = _solve_pool(self.device, masked)
-        streams, k = pool
+        streams, k, self.masked = pool
         pool[1] = (k + 1) % len(streams)
         return streams[k]
 
@@ -112,10 +132,10 @@ class CalibrationPipeline:
                solve_decoded: bool = True):
         """frames (B,3,H,W) fp32 (ToTensor's output) or (B,H,W,3) uint8 BGR (cv2.imread's / JpegDecoder.decode's
         output) on the GPU.  Enqueues forward+decode on the current stream and the solve(s) on a solve stream; returns
-        (kpts, records[, extra_records][, all_ranks_records]) device tensors (asynchronous; `join()` / `cameras()` /
-        `last_done` order a consumer behind them).  gather=True (multi-GPU): the one collective of the path --
-        every rank's per-frame records to every rank -- is enqueued on the solve stream behind the solves, so the next
-        batch's convolutions never wait for it.  solve_decoded=False (measurement aid, tools/noisy_pipeline.py): the step's ONE
+        (kpts, records[, extra_records]) device tensors (asynchronous; `join()` / `cameras()` / `last_done` order a consumer
+        behind them).  gather=True (multi-GPU): the batch's packed per-frame records (keypoints + camera records) are
+        LOGGED on the rank (dist.RecordLog, packed on the solve stream behind the solves); the one collective of the path --
+        every rank's records to every rank -- is `gather_all()`, once, after the last batch.  solve_decoded=False (measurement aid, tools/noisy_pipeline.py): the step's ONE
         solve is that of `extra_keypoints`; the records slot of the decoded keypoints is returned as None."""
         main = torch.cuda.current_stream(self.device)
         _, kpts = self.net.forward(frames, want_heat=False, decode_size=self.decode_size)
@@ -147,12 +167,14 @@ class CalibrationPipeline:
                 extra_keypoints.record_stream(side)
                 out.append(self.calibrator.solve_device(extra_keypoints))
             if gather:
-                from .dist import pack_records, gather_records
-                out.append(gather_records(pack_records(*out)))
+                from .dist import pack_records
+                self.log.add(pack_records(*[o for o in out if o is not None]))
             done = torch.cuda.Event()
             done.record(side)
         self.last_done = done               # completion of THIS batch's solves (submit.py drains batch k - 1 on it)
         self._pending.append(done)
+        if gather:
+            self._unjoined.append(done)
         if len(self._pending) > self.max_in_flight:          # bound the number of batches in flight (oldest first: in submission order)
             self._pending.pop(0).synchronize()
         return tuple(out)
@@ -163,6 +185,18 @@ class CalibrationPipeline:
         for ev in self._pending:
             cur.wait_event(ev)
         self._pending.clear()
+
+    def gather_all(self, counts=None):
+        """The path's ONE collective (multi-GPU; north_star: "a single RCCL gather over xGMI at the end"): the packed
+        records of every batch submitted with gather=True since the last call, from every rank to every rank, in frame order
+        (rank-major: a rank owns a contiguous block of frames, dist.shard_range) -> (frames of all ranks, bytes) uint8.  Enqueued on
+        the current stream behind every logged batch's solves; `counts` = frames per rank when the shards are ragged.  Without an
+        initialised process group the result is the rank's own log."""
+        cur = torch.cuda.current_stream(self.device)
+        for ev in self._unjoined:
+            cur.wait_event(ev)
+        self._unjoined.clear()
+        return self.log.gather(counts)
 
     def check_range(self):
         """Raise SncalRangeError if a forward since the last check left the split-fp16 engine's range (HRNetHeatmap.range_status):

@@ -1,6 +1,6 @@
 """GPU: the multi-GPU code path of bench.py on ONE GPU.  `SNCAL_BENCH_FORCE_DIST=1` makes a single rank take it: RCCL
-process-group init bound to the device, the per-step `all_gather_into_tensor` of the per-frame records on the pipeline's side stream
-behind the solves, the barrier and the max-over-ranks reduction -- everything the 8-GPU driver run relies on except a second rank.
+process-group init bound to the device, the records of every step logged on the rank, the ONE `all_gather_into_tensor` of all steps'
+records behind the last step's solves (CalibrationPipeline.gather_all), the barrier and the max-over-ranks reduction -- everything the 8-GPU driver run relies on except a second rank.
 The world-size-2 logic (ragged shards, frame order) is covered on gloo in tests/test_dist.py."""
 import json
 import os
@@ -34,7 +34,11 @@ def test_forced_rccl_single_rank_gather_equals_local_records(tmp_path):
     assert 'all_gather' not in line['config']['parallelism'] or line['n_gpus'] > 1          # one rank: labelled single GPU
     d = np.load(dump)
     assert int(d['world']) == 1
-    # one rank: the gathered tensor IS the rank's own records, byte for byte (keypoints 684 B + the camera record per frame)
-    assert d['gathered'].dtype == np.uint8 and d['gathered'].shape == d['local'].shape and d['local'].shape[0] == 8
+    # one rank: the gathered tensor IS the rank's own records of BOTH steps, byte for byte (keypoints 684 B + the camera record per
+    # frame), in submission order: the last 8 rows are the last step's
+    assert d['gathered'].dtype == np.uint8 and d['gathered'].shape == d['local'].shape and d['local'].shape[0] == 2 * 8
     assert np.array_equal(d['gathered'], d['local'])
+    assert np.array_equal(d['local'][8:], d['last_step'])
     assert d['local'].shape[1] > 57 * 3 * 4
+    # the collective is not part of a step: all three solve streams stay (rounds 2-5 gave RCCL one of them)
+    assert line['config']['solver']['solve_streams'] == 3

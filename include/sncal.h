@@ -14,7 +14,8 @@
  *     the stream or the device unless stated;
  *   - pointers named d_* are DEVICE pointers, h_* are HOST pointers; the library never allocates
  *     behind the caller's back on the data path: scratch comes from caller-provided workspaces
- *     whose size is returned by the matching *_workspace() query;
+ *     whose size is returned by the matching *_workspace() query (the one exception is the
+ *     convenience form sncal_calibrate, documented there; sncal_calibrate_ws follows the rule);
  *   - no torch / C++ types cross the boundary: plain pointers, ints, floats, doubles.
  */
 #ifndef SNCAL_H
@@ -132,8 +133,19 @@ int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_weight, const
  *             a layer's weight mass lies below 2^-14 (fp16's smallest normal: the halves keep fewer than 11 bits there); the message
  *             names the layer.  Callers fall back to SNCAL_F32 (the host mirror's load_model does so by itself, with a warning);
  *   forward   every kernel that splits activations counts the wavefronts that met |v| > 65504: sncal_hrnet_range_status below.
+ *   balance   (fp16x3 only, default ON) before packing, finalize rebalances block-internal channels by exact powers of two: the tensor
+ *             between conv1 and conv2 of a BasicBlock (conv1 / conv2, conv2 / conv3 of a Bottleneck; src/models/hrnet/hrnet.py:42-58, 79-99)
+ *             has ONE consumer, so producer row c x 2^-l and consumer column c x 2^l is the same fp32 network bit for bit, and choosing l so
+ *             that weight and activation are of one size keeps the fp16 halves at their full 22 bits on checkpoints whose BatchNorm scales
+ *             spread over decades (csrc/hrnet.cpp equalize_blocks; only channels >= 2^4 away from an ordinary checkpoint's balance move).
+ *             sncal_hrnet_set_equalize(net, 0) switches it off; sncal_hrnet_equalize runs the same step on its own (host only: no GPU
+ *             needed) and reports the number of channels moved; sncal_hrnet_get_conv reads a conv's host parameters back (between
+ *             sncal_hrnet_set_conv and sncal_hrnet_finalize, which releases them).  No reference counterpart (the reference is fp32).
  * A network handle is SINGLE-STREAM: forwards of one handle on two streams at once would share its work-ticket words. */
 int sncal_hrnet_finalize(sncal_hrnet* net);
+int sncal_hrnet_set_equalize(sncal_hrnet* net, int enable);
+int sncal_hrnet_equalize(sncal_hrnet* net, int* moved);
+int sncal_hrnet_get_conv(const sncal_hrnet* net, int idx, float* h_weight, float* h_scale, float* h_shift);
 /* Range flag of the split-fp16 engine since the last clear: *overflow = wavefronts that split (and clamped) an activation beyond +-65504,
  * *nonfinite = workgroups of the input layout kernel that met a NaN / infinite frame value.  Returns SNCAL_OK when both are zero,
  * SNCAL_ERR_RANGE otherwise (sncal_last_error says what to do: such forwards are not the reference's fp32 result).  Synchronises
@@ -250,12 +262,13 @@ enum {                        /* sncal_camera.status                            
     SNCAL_CAM_VOTER_HOM = 7       /* voter homography fallback  :327-329                           */
 };
 
+#define SNCAL_MAX_CONF_THRESHS 16   /* the reference loops over any number of thresholds (prediction.py:245-257); make_submit.py passes 3 */
 typedef struct {              /* CameraCreator kwargs, make_submit.py:45-50                        */
     int algorithm;            /* 0 iterative_voter, 1 original_voter, 2 voter,
                                  3 opencv_calibration, 4 opencv_calibration_multiplane            */
     int n_conf_threshs;
     double conf_thresh;       /* compared in double, like numpy's float32-scalar > python-float      */
-    double conf_threshs[4];
+    double conf_threshs[SNCAL_MAX_CONF_THRESHS];   /* iterative_voter's thresholds in the order they are tried; the first n_conf_threshs count */
     double max_rmse, max_rmse_rel;
     int min_points, min_points_per_plane, min_points_for_refinement, reliable_thresh;
     double min_focal_length;
@@ -288,12 +301,34 @@ int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pt
 /* CameraCreator.__call__  src/models/hrnet/prediction.py:130-136 with every algorithm of :90-96.
  *   d_kpts (B,57,3) fp32 decoded keypoints   d_line_pts (B,30,3) fp32 [x,y,valid] or NULL
  *   d_out (B) sncal_camera.  Never fails per frame: status 0 == the reference's `None`.
- * Asynchronous on `stream`.  iterative_voter runs as stages on that stream: the original_voter pass (two wavefronts per frame: its
- * homography camera and its calibrated camera), then, for the frames it left without a camera, one wavefront per threshold x voter
- * camera and a selection in the reference's threshold order (prediction.py:250-256); the scratch of that stage is stream-ordered
- * memory (hipMallocAsync / hipFreeAsync on `stream`), nothing persists between calls. */
+ * Asynchronous on `stream`.  iterative_voter runs as stages on that stream: the original_voter pass (one wavefront per frame and half:
+ * its homography camera and its calibrated camera), then, for the frames it left without a camera, one wavefront per threshold x voter
+ * camera and a selection in the reference's threshold order (prediction.py:250-256).
+ * Scratch (per-frame slots of the two stages):
+ *   sncal_calibrate_ws   the library's convention: the caller provides d_ws of at least sncal_calibrate_workspace(B, cfg) bytes
+ *                        (16-byte aligned device memory, free to reuse once the work enqueued on `stream` has passed it); nothing
+ *                        persists between calls.  The host mirror (CameraCreator.solve_device) uses this form.
+ *   sncal_calibrate      convenience form without a workspace argument: the library keeps ONE scratch block per (device, stream),
+ *                        hipMalloc'ed at the stream's first call, grown when a larger batch arrives, and reused by later calls on that
+ *                        stream (stream order makes that safe; rounds 3-4 took it from hipMallocAsync per call, which made the HOST wait
+ *                        for other streams' solves).  The block is released by sncal_stream_destroy(stream) for streams created here, and
+ *                        by sncal_shutdown() for all streams -- call it before destroying a stream created elsewhere whose handle value
+ *                        may be reused.
+ * RANSAC sampling -- a KNOWN DEVIATION from the reference's numbers: cv2.findHomography (src/datatools/ellipse.py:497, used through
+ * prediction.py:487-500) and cv.solvePnPRansac (baseline/camera.py:100-101) draw their minimal samples from OpenCV's fixed-seed RNG
+ * (a multiply-with-carry generator); this library draws the four indices of hypothesis h from its own counter hash of (h, draw) --
+ * the same 128 samples for every frame with the same point count, evaluated lane-parallel -- and takes the hypothesis with the most
+ * inliers (ties: smaller squared error, then lower h) where OpenCV keeps the first best and adapts its iteration count.  Both are
+ * deterministic and both refit on the winner's inliers, so on frames whose keypoints are all inliers of one model the refit -- hence the camera -- does not
+ * depend on the draw; on frames with gross outliers a different draw may find a different inlier set and therefore a different camera
+ * than OpenCV would.  Unmeasurable here (no cv2 on this image), stated so that nobody takes it for parity. */
 int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
                     sncal_camera* d_out, void* stream);
+int sncal_calibrate_workspace(int B, const sncal_voter_cfg* cfg, size_t* bytes);
+int sncal_calibrate_ws(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                       sncal_camera* d_out, void* d_ws, size_t ws_bytes, void* stream);
+/* Free what the library holds outside its handles (the scratch blocks of sncal_calibrate above); synchronises those streams. */
+int sncal_shutdown(void);
 
 /* ------------------------------------------------------------------------------------------------
  * H2 / N2  batched camera evaluation (accuracy@t of the SoccerNet calibration benchmark)

@@ -55,10 +55,13 @@ class Camera(ctypes.Structure):
                 ('n_points', ctypes.c_int32)]
 
 
+MAX_CONF_THRESHS = 16          # SNCAL_MAX_CONF_THRESHS
+
+
 class VoterCfg(ctypes.Structure):
     """sncal_voter_cfg."""
     _fields_ = [('algorithm', ctypes.c_int), ('n_conf_threshs', ctypes.c_int), ('conf_thresh', ctypes.c_double),
-                ('conf_threshs', ctypes.c_double * 4),
+                ('conf_threshs', ctypes.c_double * MAX_CONF_THRESHS),
                 ('max_rmse', ctypes.c_double), ('max_rmse_rel', ctypes.c_double),
                 ('min_points', ctypes.c_int), ('min_points_per_plane', ctypes.c_int),
                 ('min_points_for_refinement', ctypes.c_int), ('reliable_thresh', ctypes.c_int),
@@ -89,6 +92,9 @@ SIGNATURES = {
                                              ctypes.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     'sncal_hrnet_set_conv': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     'sncal_hrnet_finalize': (ctypes.c_int, [vp]),
+    'sncal_hrnet_set_equalize': (ctypes.c_int, [vp, ctypes.c_int]),
+    'sncal_hrnet_equalize': (ctypes.c_int, [vp, c_int_p]),
+    'sncal_hrnet_get_conv': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     'sncal_hrnet_range_status': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.c_int, vp]),
     'sncal_hrnet_output_size': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
     'sncal_hrnet_workspace': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -122,6 +128,9 @@ SIGNATURES = {
                                          ctypes.c_int, vp, vp]),
     'sncal_create_target': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, vp, vp]),
     'sncal_calibrate': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp]),
+    'sncal_calibrate_workspace': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(VoterCfg), ctypes.POINTER(ctypes.c_size_t)]),
+    'sncal_calibrate_ws': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(VoterCfg), vp, vp, ctypes.c_size_t, vp]),
+    'sncal_shutdown': (ctypes.c_int, []),
     'sncal_stream_create_cu_mask': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
     'sncal_stream_destroy': (ctypes.c_int, [vp]),
 }

@@ -40,6 +40,14 @@ extern "C" int sncal_stream_create_cu_mask(int cus_per_xcd, void** out) {
     return SNCAL_OK;
 }
 extern "C" int sncal_stream_destroy(void* stream) {
-    if (stream) SNCAL_CHECK_HIP(hipStreamDestroy(sncal::as_stream(stream)));
+    if (stream) {
+        sncal::release_solve_scratch(sncal::as_stream(stream), false);      // the block sncal_calibrate kept for this stream goes with it
+        SNCAL_CHECK_HIP(hipStreamDestroy(sncal::as_stream(stream)));
+    }
     return SNCAL_OK;
+}
+// Free what the library holds outside its handles: the per-(device, stream) scratch blocks of sncal_calibrate's convenience form
+// (synchronises those streams).  Network / decoder handles are released by their own destroy calls.
+extern "C" int sncal_shutdown(void) {
+    return sncal::release_solve_scratch(nullptr, true);
 }

@@ -23,6 +23,9 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// solve.hip: release the scratch block(s) sncal_calibrate keeps per (device, stream) -- one stream's, or all of them
+int release_solve_scratch(hipStream_t st, bool all);
+
 // Per-launch timing for sncal_hrnet_set_profiling: the plan executor arms a (start, stop) event pair before an op and
 // the op's launch attaches them to its dispatch (hipExtLaunchKernelGGL: timestamps of the kernel's own start and
 // completion, no extra marker packets in the queue).  SNCAL_LAUNCH_FIRST / _LAST split the pair over a two-kernel op.

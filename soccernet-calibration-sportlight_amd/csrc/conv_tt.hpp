@@ -49,6 +49,8 @@ struct TTParams {
 
 void launch_conv_tt(const TTParams& p, int n_wgs, int mode, hipStream_t s, int cfg = 0);      // mode 0 bf16, 1 fp8 (e4m3), 2 x3 (split-bf16, fp32 in / out);
                                                                                                 // cfg 0: 96 channels x 8 rows, 1: 64 x 12 (mode 2 only)
-constexpr int TT_TABLE_MAX = 760;       // sum of the members' output channels the LDS bias / scale tables hold
+constexpr int TT_TABLE_MAX = 760;       // floats per LDS table (bias, output scale)
+constexpr int TT_QUEUE_FLOATS = 16;     // the LAST 16 floats of the output-scale table are the ticket queue's four TTItem slots (conv_tt_body.inc q_slot)
+constexpr int TT_COUT_MAX = TT_TABLE_MAX - TT_QUEUE_FLOATS;      // so a (grouped) launch may hold at most this many output channels in its tables
 
 }  // namespace sncal

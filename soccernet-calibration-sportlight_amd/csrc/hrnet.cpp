@@ -151,6 +151,9 @@ struct sncal_hrnet {
     float *d_hb0 = nullptr, *d_hb1 = nullptr;
     int cur_group = GRP_ALL;
     bool finalized = false;
+    bool equalize = true;        // fp16x3: rebalance block-internal channels by powers of two at finalize (equalize_blocks)
+    bool equalize_done = false;  // ... already applied to the weights held now (re-armed by sncal_hrnet_set_conv)
+    int equalized = 0;           // channels moved by the last equalize_blocks
     int subbatch = 64;
     const ConvVariant* variants = nullptr;
     int nvariants = 0;
@@ -1534,7 +1537,7 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         // a group that mixes fp8 and bf16 members (layer selection by width) cannot share one launch: *done stays false and the
         // caller runs the members one by one (run_conv)
         if (any_fp8 && (!all_fp8 || fp8_singles)) return SNCAL_OK;
-        if (all_tt && couts <= TT_TABLE_MAX) {
+        if (all_tt && couts <= TT_COUT_MAX) {      // (the tables' last 16 floats carry the ticket queue's slots)
             const int rc = run_conv_tt(net, ops, n, (int)(ops - net.ops.data()) * 4096 + sb, sb, ws, stream);
             *done = rc == SNCAL_OK;
             return rc;
@@ -1693,6 +1696,7 @@ extern "C" int sncal_hrnet_set_conv(sncal_hrnet* net, int idx, const float* h_we
     L.shift.assign(h_shift, h_shift + L.cout);
     L.is_set = true;
     net->finalized = false;
+    net->equalize_done = false;
     return SNCAL_OK;
 }
 
@@ -1739,8 +1743,107 @@ static int x3_range_check(const sncal_hrnet& net) {
     return SNCAL_OK;
 }
 
+// Power-of-two rebalancing of block-internal channels for the split-fp16 engine.  fp16 halves carry 22 significand bits only for |v| in
+// [2^-3, 65504] and an ABSOLUTE 2^-25 below: a product w.x loses relative precision 2^-25 (1/|w| + 1/|x|), smallest when the weight and
+// the activation it meets are of one size.  A trained checkpoint need not be balanced -- a BatchNorm with a small gamma in front of a
+// convolution with large weights is the same function as the reverse (the reference computes in fp32 and cannot tell,
+// src/models/hrnet/metamodel.py:127-134) -- and measured on a four-decade spread the engine drifted to |dlogp| 5e-3 with no flag
+// (tests/test_range_guard_gpu.py).  Inside a block the balance is free to choose, EXACTLY: the output of conv1 + bn1 + ReLU of a BasicBlock
+// (conv1 / conv2 of a Bottleneck) feeds one convolution only (src/models/hrnet/hrnet.py:42-58, 79-99), ReLU commutes with a positive factor,
+// so row c of the producer (folded scale and shift) x 1/q_c and column c of the consumer x q_c, q_c a power of two, is the same network bit
+// for bit in fp32.  m_c = size of the consumer column's large folded weights (90th percentile over its output channels of the largest tap:
+// ONE outlier row -- a near-dead BatchNorm behind the consumer -- must not drag every column with it; that row is x3_range_check's to
+// refuse), a_c = |shift_c| + |row c of the producer|_2 = size of the activation for unit-size inputs, l_c = round(log2(a_c / m_c) / 2) says
+// how far apart the two are; an ordinary checkpoint (Kaiming-size weights, unit-size activations) sits at l = 2, the operating point every
+// golden and parity workload of the build was measured at.  Channels with |l_c - 2| >= 4 are brought back to it (q_c = 2^(l_c - 2));
+// everything else -- every channel of the build's own workloads -- is left untouched, bit for bit.  Tensors with several consumers
+// (module outputs, residual streams) are not rebalanced: there the two range guards apply.  Host only (no HIP call).
+// Rounds 5's host mirror did this in Python (HRNetHeatmap._equalize_blocks); it lives here so that every caller of the C ABI gets it.
+static int equalize_blocks(sncal_hrnet& net) {
+    net.equalized = 0;
+    net.equalize_done = true;
+#if SNCAL_X3_F16
+    if (!net.x3 || !net.equalize) return 0;
+    const int MIN_LOG2 = 4, CENTRE = 2;
+    auto split_name = [](const std::string& n, std::string& stem, std::string& leaf) {
+        const size_t p = n.rfind('.');
+        if (p == std::string::npos) { stem.clear(); leaf = n; } else { stem = n.substr(0, p); leaf = n.substr(p + 1); }
+    };
+    for (int i = 0; i + 1 < net.n_public; ++i) {
+        ConvLayer& P = net.layers[i];
+        ConvLayer& C = net.layers[i + 1];
+        std::string stem, leaf, nstem, nleaf;
+        split_name(P.name, stem, leaf);
+        split_name(C.name, nstem, nleaf);
+        const bool pair = (leaf == "conv1" && nleaf == "conv2") || (leaf == "conv2" && nleaf == "conv3");
+        if (P.bn.empty() || stem != nstem || stem == "model" || !pair) continue;
+        if (!P.is_set || !C.is_set || P.w.empty() || C.w.empty() || C.cin != P.cout) continue;
+        const int nch = P.cout, taps2 = C.k * C.k;
+        const size_t per1 = (size_t)P.cin * P.k * P.k;
+        std::vector<double> col(C.cout);
+        for (int c = 0; c < nch; ++c) {
+            for (int co = 0; co < C.cout; ++co) {                 // consumer column c: largest tap of every output channel, folded
+                double mx = 0;
+                const float* w = &C.w[((size_t)co * C.cin + c) * taps2];
+                for (int t = 0; t < taps2; ++t) mx = std::max(mx, std::fabs((double)w[t]));
+                col[co] = mx * std::fabs((double)C.scale[co]);
+            }
+            std::sort(col.begin(), col.end());
+            const double pos = 0.9 * (C.cout - 1);                // torch.quantile's linear interpolation
+            const int lo = (int)std::floor(pos), hi = std::min(lo + 1, C.cout - 1);
+            const double m = col[lo] + (col[hi] - col[lo]) * (pos - lo);
+            double ss = 0;                                        // producer row c: size of its output
+            const double sc = (double)P.scale[c];
+            for (size_t j = 0; j < per1; ++j) { const double v = (double)P.w[(size_t)c * per1 + j] * sc; ss += v * v; }
+            const double a = std::fabs((double)P.shift[c]) + std::sqrt(ss);
+            if (!(m > 0) || !(a > 0) || !std::isfinite(m) || !std::isfinite(a)) continue;
+            double lg = std::nearbyint(0.5 * std::log2(a / m)) - CENTRE;      // distance from the balance of an ordinary checkpoint
+            if (std::fabs(lg) < MIN_LOG2) continue;
+            lg = std::max(-60.0, std::min(60.0, lg));
+            const float q = (float)std::exp2(lg), iq = (float)std::exp2(-lg);
+            P.scale[c] *= iq;
+            P.shift[c] *= iq;
+            for (int co = 0; co < C.cout; ++co) {
+                float* w = &C.w[((size_t)co * C.cin + c) * taps2];
+                for (int t = 0; t < taps2; ++t) w[t] *= q;
+            }
+            ++net.equalized;
+        }
+    }
+#endif
+    return net.equalized;
+}
+
+extern "C" int sncal_hrnet_set_equalize(sncal_hrnet* net, int enable) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_set_equalize: null");
+    net->equalize = enable != 0;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_equalize(sncal_hrnet* net, int* moved) {
+    SNCAL_CHECK_ARG(net, "sncal_hrnet_equalize: null");
+    for (int i = 0; i < net->n_public; ++i)
+        if (!net->layers[i].is_set || net->layers[i].w.empty()) { set_error("sncal_hrnet_equalize: conv %s has no weights (call it between sncal_hrnet_set_conv and sncal_hrnet_finalize)", net->layers[i].name.c_str()); return SNCAL_ERR_STATE; }
+    if (!net->equalize_done) equalize_blocks(*net);
+    if (moved) *moved = net->equalized;
+    return SNCAL_OK;
+}
+
+extern "C" int sncal_hrnet_get_conv(const sncal_hrnet* net, int idx, float* h_weight, float* h_scale, float* h_shift) {
+    SNCAL_CHECK_ARG(net && idx >= 0 && idx < net->n_public, "sncal_hrnet_get_conv: index %d", idx);
+    const ConvLayer& L = net->layers[idx];
+    if (!L.is_set || L.w.empty()) { set_error("sncal_hrnet_get_conv: conv %s holds no host weights (they are released by sncal_hrnet_finalize)", L.name.c_str()); return SNCAL_ERR_STATE; }
+    if (h_weight) std::copy(L.w.begin(), L.w.end(), h_weight);
+    if (h_scale) std::copy(L.scale.begin(), L.scale.end(), h_scale);
+    if (h_shift) std::copy(L.shift.begin(), L.shift.end(), h_shift);
+    return SNCAL_OK;
+}
+
 extern "C" int sncal_hrnet_finalize(sncal_hrnet* net) {
     SNCAL_CHECK_ARG(net, "sncal_hrnet_finalize: null");
+    for (int i = 0; i < net->n_public; ++i)
+        if (!net->layers[i].is_set) { set_error("conv %s has no weights", net->layers[i].name.c_str()); return SNCAL_ERR_STATE; }
+    if (!net->equalize_done) equalize_blocks(*net);   // fp16x3: before the head slices are derived and the range check reads the folded weights
     // physical Cin of every conv = channel count of its input tensor
     for (const Op& op : net->ops)
         if (op.type == OP_CONV) net->layers[op.conv].cin_phys = net->tensors[op.in].C;

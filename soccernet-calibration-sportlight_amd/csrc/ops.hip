@@ -28,8 +28,11 @@ template <> struct Vec<float> {
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N,
                                                            int C, int H, int W, unsigned* __restrict__ nonfinite) {
+    // nonfinite (or null) = the second word of the network's range flag {overflow, nonfinite} (hrnet.cpp d_range; only the split-fp16
+    // engine has one): a NaN / infinite frame value bumps nonfinite[0], a finite one beyond fp16's 65504 -- which the stem's in-kernel
+    // split would clamp silently (conv.hpp) -- bumps the overflow word nonfinite[-1].  ToTensor's frames are in [0, 1]; forward() takes any fp32 tensor
     constexpr int GE = Vec<T>::GE;
-    bool bad = false;                                              // a NaN / infinite input value (the split engines' range flag, x3.hpp)
+    bool bad = false, big = false;
     const unsigned hw = (unsigned)(H * W);
     const size_t n = blockIdx.y;                                   // one image per grid row: no per-element division
     for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < hw; r += gridDim.x * 256u) {
@@ -38,11 +41,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         for (int c = 0; c < GE; ++c) {
             const float f = c < C ? x[(n * C + c) * hw + r] : 0.0f;
             bad = bad || !(__builtin_fabsf(f) <= 3.4028234663852886e38f);
+            big = big || (__builtin_fabsf(f) > 65504.0f && __builtin_fabsf(f) <= 3.4028234663852886e38f);
             v[c] = (T)f;
         }
         *reinterpret_cast<typename Vec<T>::type*>(y + (n * hw + r) * GE) = v;
     }
     if (nonfinite != nullptr && bad) atomicAdd(nonfinite, 1u);
+#if SNCAL_X3_F16
+    if (nonfinite != nullptr && big) atomicAdd(nonfinite - 1, 1u);
+#endif
 }
 
 // uint8 HWC frames (what cv2.imread hands to ToTensor, make_submit.py:62-66) -> NHWC T: ToTensor's float32 x / 255,

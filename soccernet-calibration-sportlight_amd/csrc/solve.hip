@@ -2087,31 +2087,81 @@ int ensure_pitch_uploaded() {
 // call on that stream reaches its task stage.  Rounds 3-4 took it from hipMallocAsync / hipFreeAsync per call: with the solves of
 // several batches on several streams (pipeline.py, round 5) an allocation that wants to reuse a block freed on ANOTHER stream made
 // the HOST wait for that stream's solve -- the next forward was enqueued 164 ms late, measured (tools/dev/trace_queues.py).
+namespace {
+struct ScratchBuf { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
+}
 static int voter_scratch(hipStream_t st, size_t bytes, void** out) {
-    struct Buf { void* p = nullptr; size_t bytes = 0; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
     int dev = 0;
     SNCAL_CHECK_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    Buf& b = bufs[{dev, st}];
-    if (b.bytes < bytes) {
-        if (b.p) { SNCAL_CHECK_HIP(hipStreamSynchronize(st)); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-        const size_t want = std::max(bytes, (size_t)1 << 20);
-        SNCAL_CHECK_HIP(hipMalloc(&b.p, want));
-        b.bytes = want;
+    void* old = nullptr;
+    {   std::lock_guard<std::mutex> lock(g_scratch_mu);
+        ScratchBuf& b = g_scratch[{dev, st}];
+        if (b.bytes >= bytes) { *out = b.p; return SNCAL_OK; }
+        old = b.p;                      // growth: the entry is taken out under the lock, the wait for the stream's solves happens outside it
+        b.p = nullptr; b.bytes = 0;
     }
-    *out = b.p;
+    if (old) { SNCAL_CHECK_HIP(hipStreamSynchronize(st)); (void)hipFree(old); }
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    void* p = nullptr;
+    SNCAL_CHECK_HIP(hipMalloc(&p, want));
+    {   std::lock_guard<std::mutex> lock(g_scratch_mu);
+        ScratchBuf& b = g_scratch[{dev, st}];
+        if (b.p) {                      // another thread grew the same (device, stream) entry meanwhile: keep the larger block
+            if (b.bytes >= want) { (void)hipFree(p); *out = b.p; return SNCAL_OK; }
+            void* q = b.p; b.p = nullptr;
+            (void)hipStreamSynchronize(st); (void)hipFree(q);
+        }
+        b.p = p; b.bytes = want;
+    }
+    *out = p;
     return SNCAL_OK;
 }
 
-extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
-                               sncal_camera* d_out, void* stream) {
+namespace sncal {
+// sncal_stream_destroy / sncal_shutdown: the convenience form of sncal_calibrate keeps one scratch block per (device, stream); a stream
+// that is destroyed takes its block with it (a later stream at the same address must not inherit a block the old stream's kernels may
+// still be using: the release synchronises the stream first).  st == nullptr with all == true: every block of every device.
+int release_solve_scratch(hipStream_t st, bool all) {
+    std::vector<std::pair<std::pair<int, hipStream_t>, void*>> victims;
+    {   std::lock_guard<std::mutex> lock(g_scratch_mu);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+            if (all || it->first.second == st) { if (it->second.p) victims.push_back({it->first, it->second.p}); it = g_scratch.erase(it); }
+            else ++it;
+        }
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& v : victims) {
+        (void)hipSetDevice(v.first.first);
+        (void)hipStreamSynchronize(v.first.second);
+        (void)hipFree(v.second);
+    }
+    (void)hipSetDevice(cur);
+    return SNCAL_OK;
+}
+}  // namespace sncal
+
+static size_t calibrate_fp_bytes(int B) { return ((size_t)B * sizeof(FirstPass) + 255) & ~(size_t)255; }
+static size_t calibrate_ws_bytes(int B, const sncal_voter_cfg* cfg) {
+    return calibrate_fp_bytes(B) + (size_t)B * std::max(cfg->n_conf_threshs, 1) * sizeof(VoterShared);
+}
+
+extern "C" int sncal_calibrate_workspace(int B, const sncal_voter_cfg* cfg, size_t* bytes) {
+    SNCAL_CHECK_ARG(B >= 0 && cfg && bytes, "sncal_calibrate_workspace: bad arguments");
+    SNCAL_CHECK_ARG(cfg->n_conf_threshs >= 0 && cfg->n_conf_threshs <= SNCAL_MAX_CONF_THRESHS, "sncal_calibrate_workspace: n_conf_threshs");
+    *bytes = std::max(calibrate_ws_bytes(B, cfg), (size_t)256);
+    return SNCAL_OK;
+}
+
+static int calibrate_impl(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                          sncal_camera* d_out, void* d_ws, size_t ws_bytes, bool own_ws, void* stream) {
     SNCAL_CHECK_ARG(B >= 0 && cfg, "sncal_calibrate: bad arguments");
     if (B == 0) return SNCAL_OK;
     SNCAL_CHECK_ARG(d_kpts && d_out, "sncal_calibrate: null pointer");
     SNCAL_CHECK_ARG(cfg->algorithm >= 0 && cfg->algorithm <= 4, "sncal_calibrate: algorithm %d", cfg->algorithm);
-    SNCAL_CHECK_ARG(cfg->n_conf_threshs >= 0 && cfg->n_conf_threshs <= 4, "sncal_calibrate: n_conf_threshs");
+    SNCAL_CHECK_ARG(cfg->n_conf_threshs >= 0 && cfg->n_conf_threshs <= SNCAL_MAX_CONF_THRESHS, "sncal_calibrate: n_conf_threshs");
     SNCAL_CHECK_ARG(cfg->img_w > 1 && cfg->img_h > 1, "sncal_calibrate: image size");
     const int rc = ensure_pitch_uploaded();
     if (rc) return rc;
@@ -2125,11 +2175,16 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
     // aid / A-B reference, also what the byte-identity test compares with): round 4's paired 256-thread calibrate_kernel
     static const bool wave_wgs = !(getenv("SNCAL_SOLVE_WAVE_WGS") && atoi(getenv("SNCAL_SOLVE_WAVE_WGS")) == 0);
     const bool paired = cfg->algorithm <= 1;
-    // scratch of the stream: the first pass's per-frame slots, then the voter's per-(frame, threshold) slots
-    const size_t fp_bytes = ((size_t)B * sizeof(FirstPass) + 255) & ~(size_t)255;
-    char* scratch = nullptr;
-    {   const int rcs = voter_scratch(st, fp_bytes + (size_t)B * std::max(cfg->n_conf_threshs, 1) * sizeof(VoterShared), reinterpret_cast<void**>(&scratch));
+    // scratch: the first pass's per-frame slots, then the voter's per-(frame, threshold) slots -- the caller's workspace
+    // (sncal_calibrate_ws) or the stream's own block (sncal_calibrate)
+    const size_t fp_bytes = calibrate_fp_bytes(B);
+    char* scratch = reinterpret_cast<char*>(d_ws);
+    if (own_ws) {
+        const int rcs = voter_scratch(st, calibrate_ws_bytes(B, cfg), reinterpret_cast<void**>(&scratch));
         if (rcs) return rcs;
+    } else {
+        SNCAL_CHECK_ARG(d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 15) == 0, "sncal_calibrate_ws: workspace pointer (16-byte aligned device memory)");
+        if (ws_bytes < calibrate_ws_bytes(B, cfg)) { sncal::set_error("sncal_calibrate_ws: workspace of %zu bytes, %zu needed (sncal_calibrate_workspace)", ws_bytes, calibrate_ws_bytes(B, cfg)); return SNCAL_ERR_WORKSPACE; }
     }
     if (paired && wave_wgs && (cfg->algorithm == 1 || defer)) {
         FirstPass* fp = reinterpret_cast<FirstPass*>(scratch);
@@ -2162,6 +2217,16 @@ extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int
         }
     }
     return SNCAL_OK;
+}
+
+extern "C" int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                               sncal_camera* d_out, void* stream) {
+    return calibrate_impl(d_kpts, d_line_pts, B, cfg, d_out, nullptr, 0, true, stream);
+}
+
+extern "C" int sncal_calibrate_ws(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
+                                  sncal_camera* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    return calibrate_impl(d_kpts, d_line_pts, B, cfg, d_out, d_ws, ws_bytes, false, stream);
 }
 
 static int env_schedule() {       // SNCAL_SOLVE_SCHEDULE=converged: the two single-camera entries on the run-to-convergence minimisers

@@ -121,6 +121,8 @@ class HRNetHeatmap:
         self.num_classes = desc.num_classes
         self._ws = None
         self._loaded = False
+        self.equalize = True         # fp16x3: load-time rebalancing of block-internal channels (sncal_hrnet_set_equalize)
+        self.equalized = 0
 
     def __del__(self):
         try:
@@ -145,10 +147,19 @@ class HRNetHeatmap:
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference's nn_state_dict (keys 'model.conv1.weight', ... metamodel.py:108-124)."""
+        self.set_convs(state_dict, strict)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sncal_hrnet_finalize(self._h), 'sncal_hrnet_finalize')
+        self._loaded = True
+        return self
+
+    def set_convs(self, state_dict, strict: bool = True):
+        """The host half of load_state_dict (no GPU needed): eval-mode BatchNorm folded in fp64, every conv unit handed to the library
+        (sncal_hrnet_set_conv), and -- fp16x3 -- the library's power-of-two rebalancing of block-internal channels
+        (sncal_hrnet_equalize; `equalized` = channels moved).  load_state_dict = set_convs + sncal_hrnet_finalize."""
         sd = {k.replace('_orig_mod.', ''): v for k, v in state_dict.items()}
         used = set()
         units = self.conv_units()
-        folded = []                                       # per unit: [weight fp64 (cout, cin, k, k), scale fp64, shift fp64]
         for i, (name, bn, cin, cout, k, stride, has_bias) in enumerate(units):
             w = sd[name + '.weight'].detach().to('cpu', torch.float64)
             used.add(name + '.weight')
@@ -169,9 +180,6 @@ class HRNetHeatmap:
             else:
                 scale = torch.ones(cout, dtype=torch.float64)
                 shift = b
-            folded.append([w.clone(), scale, shift])
-        self.equalized = self._equalize_blocks(units, folded) if self.dtype_name == 'fp16x3' else 0
-        for i, (w, scale, shift) in enumerate(folded):
             wf = np.ascontiguousarray(w.to(torch.float32).numpy())
             sc = np.ascontiguousarray(scale.to(torch.float32).numpy())
             sh = np.ascontiguousarray(shift.to(torch.float32).numpy())
@@ -180,49 +188,22 @@ class HRNetHeatmap:
             extra = [k for k in sd if k not in used and not k.endswith('num_batches_tracked')]
             if extra:
                 raise _lib.SncalError(f'unexpected keys in state dict: {extra[:5]}...')
-        with torch.cuda.device(self.device):
-            _lib.check(self._L.sncal_hrnet_finalize(self._h), 'sncal_hrnet_finalize')
-        self._loaded = True
+        # fp16x3: block-internal channels are rebalanced by exact powers of two inside the library (sncal_hrnet_equalize = the first step
+        # of sncal_hrnet_finalize; sncal.h "balance"), so that a caller of the C ABI gets what load_model gets
+        _lib.check(self._L.sncal_hrnet_set_equalize(self._h, int(self.equalize)), 'sncal_hrnet_set_equalize')
+        moved = ctypes.c_int()
+        _lib.check(self._L.sncal_hrnet_equalize(self._h, ctypes.byref(moved)), 'sncal_hrnet_equalize')
+        self.equalized = moved.value
         return self
 
-    @staticmethod
-    def _equalize_blocks(units, folded, min_log2: int = 4, centre: int = 2):
-        """Power-of-two rebalancing of block-internal channels for the split-fp16 engine (round 5).  fp16 halves carry 22 bits only for
-        |v| in [2^-3, 65504] and an ABSOLUTE 2^-25 below: a product w.x loses relative precision 2^-25 (1/|w| + 1/|x|), smallest when the
-        weight and the activation it meets are of one size.  A trained checkpoint need not be balanced -- a BatchNorm with a small gamma
-        in front of a convolution with large weights is the same function as the reverse -- and measured on a four-decade spread the engine
-        drifted to |dlogp| 5e-3 without any flag (tests/test_range_guard_gpu.py).  Inside a block the balance is free to choose, EXACTLY:
-        the output of conv1 + bn1 + ReLU of a BasicBlock (conv1 / conv2 of a Bottleneck) feeds one convolution only (hrnet.py:42-58, 79-99),
-        ReLU commutes with a positive factor, so row c of the producer (folded scale and shift) x 1/q_c and column c of the consumer x q_c,
-        q_c a power of two, is the same network bit for bit in fp32.  With m_c the size of the consumer column's large folded weights (90th percentile over its output channels) and
-        a_c = |shift_c| + |row c of the producer|_2 the size of the activation (unit-size inputs), l_c = round(log2(a_c / m_c) / 2) says how far
-        the two are apart; an ordinary checkpoint (Kaiming-size weights, unit-size activations) sits at l = `centre` = 2, the operating point
-        all goldens and parity workloads of the build were measured at.  Channels with |l_c - centre| >= min_log2 are brought back to it:
-        q_c = 2^(l_c - centre); everything else -- every channel of the build's own workloads -- is left untouched, bit for bit.
-        Tensors with several consumers (module outputs, the residual streams) are not rebalanced.  Returns the number of channels moved."""
-        moved = 0
-        for i in range(len(units) - 1):
-            name, bn, nxt = units[i][0], units[i][1], units[i + 1][0]
-            stem, leaf = name.rsplit('.', 1)
-            nstem, nleaf = nxt.rsplit('.', 1)
-            if not bn or stem != nstem or stem == 'model' or (leaf, nleaf) not in (('conv1', 'conv2'), ('conv2', 'conv3')):
-                continue
-            w1, sc1, sh1 = folded[i]
-            w2, sc2, _ = folded[i + 1]
-            m = (w2.abs() * sc2.abs().view(-1, 1, 1, 1)).amax(dim=(2, 3)).quantile(0.9, dim=0)   # consumer column c: its large folded weights
-            #   (90th percentile over the output channels of the largest tap, not the maximum: ONE outlier row -- a near-dead BatchNorm behind the consumer -- must not
-            #   drag every column down with it; that row is for sncal_hrnet_finalize's range check to refuse)
-            a = sh1.abs() + torch.sqrt((w1 * sc1.view(-1, 1, 1, 1)).pow(2).sum(dim=(1, 2, 3)))     # producer row c: size of its output
-            ok = (m > 0) & (a > 0) & torch.isfinite(m) & torch.isfinite(a)
-            lg = torch.where(ok, torch.round(0.5 * torch.log2(torch.where(ok, a / torch.where(ok, m, torch.ones_like(m)), torch.ones_like(a)))), torch.zeros_like(a))
-            lg = lg - centre                                   # distance from the balance of an ordinary checkpoint
-            lg = torch.where(lg.abs() >= min_log2, lg, torch.zeros_like(lg)).clamp(-60, 60)
-            q = torch.exp2(lg)
-            folded[i][1] = sc1 / q
-            folded[i][2] = sh1 / q
-            folded[i + 1][0] = w2 * q.view(1, -1, 1, 1)
-            moved += int((lg != 0).sum())
-        return moved
+    def folded_conv(self, idx):
+        """(weight (cout,cin,k,k), scale (cout), shift (cout)) fp32 numpy of conv unit `idx` as the library holds them between
+        sncal_hrnet_set_conv and sncal_hrnet_finalize (test instrumentation: the rebalanced parameters)."""
+        name, bn, cin, cout, k, stride, has_bias = self.conv_units()[idx]
+        w = np.empty((cout, cin, k, k), dtype=np.float32)
+        sc, sh = np.empty(cout, dtype=np.float32), np.empty(cout, dtype=np.float32)
+        _lib.check(self._L.sncal_hrnet_get_conv(self._h, idx, w.ctypes.data, sc.ctypes.data, sh.ctypes.data), 'sncal_hrnet_get_conv')
+        return w, sc, sh
 
     # ---- forward --------------------------------------------------------------------------------
     def output_size(self, H, W):

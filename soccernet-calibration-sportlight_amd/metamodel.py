@@ -32,20 +32,27 @@ class HRNetMetaModel:
         pt = _plain(params.get('prediction_transform', {}) or {})
         self.prediction_transform = self.prediction_transform_cls(**pt) if pt else None
 
-    def predict(self, x: torch.Tensor) -> torch.Tensor:
-        """x (B,3,H,W) float32 BGR in [0,1] (any device) -> prediction_transform(net(x)[-1]) on `device`."""
+    def predict(self, x: torch.Tensor, check_range: bool = True) -> torch.Tensor:
+        """x (B,3,H,W) float32 BGR in [0,1] (any device) -> prediction_transform(net(x)[-1]) on `device`.
+        On the split-fp16 engine the range flag of THIS call is read before the result is handed out (SncalRangeError on the
+        offending call, never one call late): that waits for the forward, which the reference's only callers do anyway on the next
+        line (`.cpu().numpy()`, make_submit.py:68-69, export_line_result.py:181).  check_range=False returns without waiting; the
+        caller then owes a check_range() before trusting the results."""
         if self.prediction_transform is None:
             raise _lib.SncalError('predict(): params hold no prediction_transform')
         x = x.to(self.device, non_blocking=True)
-        self.check_range()              # the range flag of the PREVIOUS calls (their results have been consumed by now: no stall)
         pt = self.prediction_transform
         if isinstance(pt, HRNetPredictionTransform):     # fused: decode straight from the engine
-            return self.nn_module.forward(x, want_heat=False, decode_size=(pt.H, pt.W))[1]
-        return pt(self.nn_module(x)[-1])
+            out = self.nn_module.forward(x, want_heat=False, decode_size=(pt.H, pt.W))[1]
+        else:
+            out = pt(self.nn_module(x)[-1])
+        if check_range:
+            self.check_range()
+        return out
 
     def check_range(self):
         """Raise SncalRangeError if a forward since the last check left the split-fp16 engine's range (HRNetHeatmap.range_status):
-        its output was NOT the reference's fp32 result.  predict() checks the calls before it; call this after the last one."""
+        its output was NOT the reference's fp32 result.  Synchronises the current stream.  predict() calls it on its own forward."""
         if self.nn_module.dtype_name == 'fp16x3':
             self.nn_module.range_status(clear=True, check=True)
 

@@ -98,8 +98,8 @@ class CameraCreator:
         c.algorithm = ALGORITHMS[self.algorithm_name]
         c.conf_thresh = float(self.conf_thresh)
         ths = list(self.conf_threshs)
-        if len(ths) > 4:       # sncal_voter_cfg carries four thresholds; the reference loops over any number (prediction.py:245-257)
-            raise _lib.SncalError(f'conf_threshs holds {len(ths)} thresholds; sncal_voter_cfg carries at most 4')
+        if len(ths) > _lib.MAX_CONF_THRESHS:       # the reference loops over any number (prediction.py:245-257); make_submit.py passes 3
+            raise _lib.SncalError(f'conf_threshs holds {len(ths)} thresholds; sncal_voter_cfg carries at most {_lib.MAX_CONF_THRESHS}')
         c.n_conf_threshs = len(ths)
         for i, t in enumerate(ths):
             c.conf_threshs[i] = float(t)
@@ -128,7 +128,9 @@ class CameraCreator:
 
     def solve_device(self, d_kpts, d_line_pts=None, out=None):
         """Batched solve on device tensors: d_kpts (B,57,3) float32 cuda -> uint8 cuda tensor of B sncal_camera
-        records (asynchronous on the current stream)."""
+        records (asynchronous on the current stream).  The solve's scratch is a workspace tensor of this call
+        (sncal_calibrate_workspace / sncal_calibrate_ws: the library allocates nothing), taken from torch's caching allocator on the
+        current stream -- stream-ordered reuse, no hipMalloc in steady state, no host wait for another stream's solves."""
         import torch
         _lib.require_device(d_kpts, torch.float32, 'kpts')
         B = d_kpts.shape[0]
@@ -139,10 +141,14 @@ class CameraCreator:
         if out is None:
             out = torch.empty((B, ctypes.sizeof(_lib.Camera)), dtype=torch.uint8, device=d_kpts.device)
         cfg = self._cfg()
+        n = ctypes.c_size_t()
+        _lib.check(_lib.lib().sncal_calibrate_workspace(B, ctypes.byref(cfg), ctypes.byref(n)), 'sncal_calibrate_workspace')
         with torch.cuda.device(d_kpts.device):
-            _lib.check(_lib.lib().sncal_calibrate(d_kpts.data_ptr(), d_line_pts.data_ptr() if d_line_pts is not None else None,
-                                                  B, ctypes.byref(cfg), out.data_ptr(), _lib.current_stream_ptr()),
-                       'sncal_calibrate')
+            ws = torch.empty(n.value, dtype=torch.uint8, device=d_kpts.device)
+            _lib.check(_lib.lib().sncal_calibrate_ws(d_kpts.data_ptr(), d_line_pts.data_ptr() if d_line_pts is not None else None,
+                                                     B, ctypes.byref(cfg), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     _lib.current_stream_ptr()),
+                       'sncal_calibrate_ws')
         return out
 
     @staticmethod

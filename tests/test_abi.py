@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,7 +37,49 @@ def test_struct_layouts_match_the_header():
     L = sncal_amd._lib
     assert ctypes.sizeof(L.Camera) == 3 * 8 + 9 * 8 + 5 * 8 + 2 * 4          # sncal_camera
     assert ctypes.sizeof(L.HRNetDesc) == (6 + 3 + 3 + 3 + 12) * 4            # sncal_hrnet_desc
-    assert ctypes.sizeof(L.VoterCfg) == 8 + 8 + 32 + 16 + 4 * 4 + 8 + 8 + 8  # sncal_voter_cfg (img_w, img_h, lm_schedule, refine_max_iters last)
+    assert ctypes.sizeof(L.VoterCfg) == 8 + 8 + 16 * 8 + 16 + 4 * 4 + 8 + 8 + 8  # sncal_voter_cfg (img_w, img_h, lm_schedule, refine_max_iters last)
+
+
+def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
+    """sizeof / offsetof of every struct of include/sncal.h as gcc lays it out == the ctypes mirrors, field by field; and the
+    VoterCfg binding INTEGRATION.md shows a maintainer == the header's struct (the snippet was two fields short)."""
+    import re
+    import shutil
+    import subprocess
+    import sncal_amd
+    L = sncal_amd._lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    structs = {'sncal_voter_cfg': L.VoterCfg, 'sncal_camera': L.Camera, 'sncal_hrnet_desc': L.HRNetDesc, 'sncal_kernel_stat': L.KernelStat,
+               'sncal_plan_op': L.PlanOp, 'sncal_plan_tensor': L.PlanTensor}
+    rename = {'in_': 'in'}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "' + os.path.join(ROOT, 'include', 'sncal.h') + '"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in ct._fields_:
+            fn = rename.get(f[0], f[0])
+            lines.append(f'  printf("{cname}.{f[0]} %zu\\n", offsetof({cname}, {fn}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call([gcc, str(src), '-o', str(exe)])
+    seen = dict(ln.split() for ln in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, ct in structs.items():
+        assert int(seen[cname]) == ctypes.sizeof(ct), cname
+        for f in ct._fields_:
+            assert int(seen[f'{cname}.{f[0]}']) == getattr(ct, f[0]).offset, (cname, f[0])
+    # the binding INTEGRATION.md shows
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'class VoterCfg\(ctypes\.Structure\):.*?\n(    _fields_ = \[.*?\]\s*(?:#[^\n]*)?)\n(?=cfg = )', text, re.S)
+    assert m, 'INTEGRATION.md no longer shows the VoterCfg binding'
+    ns = {'ctypes': ctypes}
+    exec('class VoterCfg(ctypes.Structure):\n' + m.group(1), ns)
+    doc = ns['VoterCfg']
+    assert [f[0] for f in doc._fields_] == [f[0] for f in L.VoterCfg._fields_]
+    assert ctypes.sizeof(doc) == ctypes.sizeof(L.VoterCfg)
+    assert all(getattr(doc, f[0]).offset == getattr(L.VoterCfg, f[0]).offset for f in doc._fields_)
 
 
 def test_plan_enumeration_matches_the_oracle_without_a_gpu():
@@ -266,4 +309,6 @@ def test_config_mappings_that_are_not_dicts():
     with pytest.raises(sncal_amd._lib.SncalError):
         H.load_config('no_such_config_name')
     with pytest.raises(sncal_amd._lib.SncalError):                       # more thresholds than the C struct carries
-        sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_threshs=[0.5, 0.4, 0.3, 0.2, 0.1])._cfg()
+        sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_threshs=[0.9 - 0.05 * i for i in range(17)])._cfg()
+    c5 = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_threshs=[0.5, 0.4, 0.3, 0.2, 0.1])._cfg()     # the reference loops over any number
+    assert c5.n_conf_threshs == 5 and list(c5.conf_threshs)[:5] == [0.5, 0.4, 0.3, 0.2, 0.1]

@@ -90,6 +90,42 @@ def test_run_time_flag_counts_clamped_activations_and_nonfinite_inputs(sncal, cu
     net.forward(xb, want_heat=False, decode_size=(540, 960))
     ov, nf = net.range_status()
     assert nf > 0
+    # a FINITE frame value beyond 65504 (forward() takes any fp32 tensor, not only ToTensor's [0, 1]): the stem's in-kernel split would
+    # clamp it silently -- the input layout kernel counts it as an overflow
+    xh = x.clone()
+    xh[0, 1, 40, 80] = 7.0e4
+    net.forward(xh, want_heat=False, decode_size=(540, 960))
+    ov, nf = net.range_status()
+    assert ov > 0 and nf == 0
+    n32f = _nets(sncal, cuda, sd, 'fp32')
+    n32f.forward(xh, want_heat=False, decode_size=(540, 960))
+    assert n32f.range_status() == (0, 0)
+
+
+def test_predict_raises_on_the_offending_call_not_one_call_late(sncal, cuda, tmp_path):
+    """predict() used to check the flag of the calls BEFORE it, so the last or only predict() of a run was never
+    checked.  The drop-in surface is load_model(...).predict(x) (make_submit.py:51,68)."""
+    cfg = hr.load_config('hrnet_w18')
+    sd = hr.seeded_state_dict(cfg, 5, 4.0)
+    hot = {k: v.clone() for k, v in sd.items()}
+    hot['model.bn1.weight'] *= 2.0 ** 15
+    hot['model.bn1.bias'] *= 2.0 ** 15
+    hot['model.conv2.weight'] *= 2.0 ** -6
+    params = {'nn_module': {'hrnet_config': cfg, 'num_refinement_stages': 0, 'num_heatmaps': 58},
+              'prediction_transform': {'size': [540, 960]}, 'device': 'cuda:0'}
+    x = hr.seeded_input(2, 135, 240, 6)
+    path = str(tmp_path / 'hot.pth')
+    torch.save({'model_name': 'HRNetMetaModel', 'params': params, 'nn_state_dict': hot}, path)
+    model = sncal.load_model(path, device='cuda:0', dtype='fp16x3')
+    with pytest.raises(sncal._lib.SncalRangeError):
+        model.predict(x)                                    # the FIRST and only call
+    assert model.predict(x, check_range=False).shape == (2, 57, 3)      # opt-out: no wait, the caller owes the check
+    with pytest.raises(sncal._lib.SncalRangeError):
+        model.check_range()
+    path = str(tmp_path / 'ok.pth')
+    torch.save({'model_name': 'HRNetMetaModel', 'params': params, 'nn_state_dict': sd}, path)
+    good = sncal.load_model(path, device='cuda:0')
+    assert good.predict(x).shape == (2, 57, 3) and good.predict(x).shape == (2, 57, 3)
 
 
 def test_pipeline_and_predict_surface_raise_on_the_flag(sncal, cuda):

@@ -15,18 +15,18 @@ dev = torch.device('cuda:0')
 sd = sncal_amd.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True, row_gain=row_gain)
 # PARITY_TRAINED_LIKE=<seed>: the same function with a trained checkpoint's spread of scales -- every block-internal channel x 2^k, k ~ N(0, 3)
 # (four decades), 2 % near-dead channels at 2^-12, the next convolution's column x 2^-k (synth.rescaled_state_dict: bit-identical in fp32).
-# PARITY_NO_EQUALIZE=1 switches the load-time rebalancing of the fp16x3 engine off (HRNetHeatmap._equalize_blocks): what it is there for.
+# PARITY_NO_EQUALIZE=1 switches the load-time rebalancing of the fp16x3 engine off (sncal_hrnet_set_equalize(net, 0)): what it is there for.
 trained_like = os.environ.get('PARITY_TRAINED_LIKE')
 if trained_like is not None:
     units = sncal_amd.HRNetHeatmap('hrnet_w48', dtype='fp32', device='cpu').conv_units()
     sd = sncal_amd.synth.rescaled_state_dict(sd, units, seed=int(trained_like), sigma_log2=3.0, dead_frac=0.02)
-if os.environ.get('PARITY_NO_EQUALIZE') == '1':
-    sncal_amd.HRNetHeatmap._equalize_blocks = staticmethod(lambda units, folded, **kw: 0)
+NO_EQUALIZE = os.environ.get('PARITY_NO_EQUALIZE') == '1'
 cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **bench.SOLVER_KW)
 res = {}
 kps = {}
 for dtype in ('fp32', 'fp16x3', 'bf16'):
     net = sncal_amd.HRNetHeatmap('hrnet_w48', dtype=dtype, device=dev)
+    net.equalize = not NO_EQUALIZE
     try:
         net.load_state_dict(sd)
     except sncal_amd._lib.SncalRangeError as e:

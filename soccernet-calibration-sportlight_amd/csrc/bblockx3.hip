@@ -58,7 +58,10 @@ constexpr int M_PITCH = MW * PXB, M_PLANE = MH * M_PITCH;
 constexpr int RING_SLOTS = 4;                       // 2 x BBX_STEPS is a multiple: a step's slot is a compile-time constant
 constexpr int OFF_X = 0, OFF_M = OFF_X + 2 * X_PLANE, OFF_RING = OFF_M + 2 * M_PLANE;
 constexpr int OFF_BIAS = OFF_RING + RING_SLOTS * BBX_STEP_BYTES, OFF_CTRL = OFF_BIAS + 96 * 4, LDS_BYTES = OFF_CTRL + 96;
-constexpr int NW = 8;                               // multiplying waves (two per SIMD); wave NW streams the weights, wave NW + 1 the x halos
+#ifndef BBX_NW
+#define BBX_NW 8
+#endif
+constexpr int NW = BBX_NW;                          // multiplying waves (8: two per SIMD; 4: one per SIMD, twice the rows each); wave NW streams the weights, wave NW + 1 the x halos
 constexpr int J1 = (MH + NW - 1) / NW, J2 = TH / NW;                          // pixel fragments (tile rows) per wave: conv1 (at most), conv2
 constexpr int NSUB = 3 * BBX_STEPS - 1;             // sub-steps of a convolution: (cross u0, cross u1, main) per step, no cross for the zero unit
 static_assert(XH * X_PITCH <= X_PLANE && (2 * BBX_STEPS) % RING_SLOTS == 0 && TH % NW == 0 && J1 == J2 + 1 && LDS_BYTES <= 160 * 1024, "layout");

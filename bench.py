@@ -23,7 +23,7 @@ Engine.  The benchmarked engine is `fp16x3` (default, and load_model's default):
 formed on the 16-bit matrix pipe from split operands (x = hi + lo, two fp16; hi.hi + hi.lo + lo.hi: the dropped term is ~2^-22 of a
 product) -- the fastest engine of the build that returns the fp32 engine's keypoint indices (the reference's predict() is fp32,
 metamodel.py:127-134; north_star asks for bit-identical indices): all usable keypoints of the benchmarked frames (`parity` on the
-line) and 39 642 of 39 642 on 2048 frames with 2045 of 2045 cameras identical (tools/parity_large.py).  `roofline.peak`
+line) and 39 642 of 39 642 on 2048 frames with 2045 of 2045 cameras identical (tools/parity_large.py, NOTES/design_history_r1_r5.md §10).  `roofline.peak`
 is the 16-bit dense MFMA peak / 3 (three executed products per reference product); `roofline.frac_of_16bit_dense_peak` prices the
 same reference-formulation work against the undivided hardware peak.  The bf16 throughput engine (2.6x faster, 1-3 % of the usable
 keypoints move by one cell on this workload) and the exact-fp32 engine are timed on the same frames outside the timed region and
@@ -449,11 +449,16 @@ def main():
     ap.add_argument('--workload', default='c3', choices=['c3', 'c4'],
                     help='c3: HRNet-W48 keypoint net + decode + solve (the metric\'s configuration); c4: + the W48 line net, '
                          'its two-peak decode and the device line join in front of the solve')
+    ap.add_argument('--line-workload', default='designed', choices=['designed', 'random'],
+                    help="--workload c4: 'designed' = the line network carries the same deep signal path as the keypoint network and answers with the "
+                         "lines through the stamped keypoints (synth.line_deep_state_dict), joined at get_line_data's own prob_thre 0.2: line points "
+                         "consistent with the frame, as a trained line network gives; 'random' = the raw random-init line network at the export "
+                         "CLI's prob_thre 0 (rounds 2-5): 28 garbage line points per frame, a stress case for the solve (most fits crawl)")
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--lanes', type=int, default=1,
-                    help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md 5: '
+                    help='split the batch into this many independent sub-batches on their own streams (default 1; see DESIGN.md §5: '
                          '2 lanes fill kernel tails and launch gaps, but per-kernel HIP-event durations then measure a shared GPU, '
                          'so the roofline object is only meaningful at 1)')
     ap.add_argument('--dump-gather', default=None,
@@ -496,6 +501,9 @@ def main():
         raise SystemExit(f'--batch {B} is not a multiple of --lanes {L}')
     c4 = args.workload == 'c4'
     sd_line = seeded_weights('line_hrnet_w48', seed=2) if c4 else None
+    if c4 and args.line_workload == 'designed':
+        sd_line = sncal_amd.synth.line_deep_state_dict(sd_line)
+    line_prob_thre = 0.2 if args.line_workload == 'designed' else 0.0
     nets, lnets = [], []
     for _ in range(L):
         net = sncal_amd.HRNetHeatmap(cfg_name, dtype=args.dtype, device=dev)
@@ -517,7 +525,7 @@ def main():
             n.calibrate_fp8(x[:4])
             n.set_fp8_layers(args.fp8_layers)
     cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, **SOLVER_KW)
-    pipes = [sncal_amd.CalibrationPipeline(nets[i], cc, decode_size=(540, 960), line_net=lnets[i] if c4 else None)
+    pipes = [sncal_amd.CalibrationPipeline(nets[i], cc, decode_size=(540, 960), line_net=lnets[i] if c4 else None, line_prob_thre=line_prob_thre)
              for i in range(L)]
     lane_streams = [None] if L == 1 else [torch.cuda.Stream(device=dev) for _ in range(L)]
     bl = B // L
@@ -686,6 +694,7 @@ def main():
         dtype_label = args.dtype + (f' (fp8 layers: {args.fp8_layers})' if args.dtype == 'fp8' else '')
         wl = (f'C5: HRNet-W48 1920x1080, batch {B} per GPU, {dtype_label}, heatmap 540x960 + decode + batched camera solve (iterative_voter)'
               if args.size == '1080p' else 'C4: HRNet-W48 keypoint net + HRNet-W48 line net, 960x540, batch 64 per GPU, decodes + device line join + batched camera solve (iterative_voter)'
+                                     + (' [line network: designed signal path, line join at prob_thre 0.2]' if args.line_workload == 'designed' else ' [line network: raw random init, prob_thre 0: garbage line points, solve stress case]')
               if c4 else 'C3: HRNet-W48 960x540, batch 64 per GPU, heatmap + decode + batched camera solve (iterative_voter) on the decoded keypoints')
         out = {
             'metric': 'frames/sec (HRNet-W48 960x540 + PnP)', 'value': round(world * B * args.steps / dt, 2),

@@ -47,7 +47,7 @@ int sncal_version(void);
 const char* sncal_last_error(void);
 /* Name of the split-arithmetic engine this library was built with (SNCAL_BF16X3): "fp16x3" (fp16 hi + fp16 lo, the default since round 4)
  * or "bf16x3" (bf16 hi + lo, -DSNCAL_X3_F16=0).  No reference counterpart: the reference's predict() is plain fp32
- * (src/models/hrnet/metamodel.py:127-134); the engine reproduces it on the 16-bit matrix pipe. */
+ * (src/models/hrnet/metamodel.py:127-134); the engine reproduces it on the 16-bit matrix pipe (NOTES/design_history_r1_r5.md §9.3 / 10). */
 const char* sncal_x3_name(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -321,7 +321,7 @@ int sncal_solve_pnp(const double* d_K, const double* d_pts3d, const double* d_pt
  * inliers (ties: smaller squared error, then lower h) where OpenCV keeps the first best and adapts its iteration count.  Both are
  * deterministic and both refit on the winner's inliers, so on frames whose keypoints are all inliers of one model the refit -- hence the camera -- does not
  * depend on the draw; on frames with gross outliers a different draw may find a different inlier set and therefore a different camera
- * than OpenCV would.  Unmeasurable here (no cv2 on this image; DESIGN.md 2), stated so that nobody takes it for parity. */
+ * than OpenCV would.  Unmeasurable here (no cv2 on this image; DESIGN.md §2), stated so that nobody takes it for parity. */
 int sncal_calibrate(const float* d_kpts, const float* d_line_pts, int B, const sncal_voter_cfg* cfg,
                     sncal_camera* d_out, void* stream);
 int sncal_calibrate_workspace(int B, const sncal_voter_cfg* cfg, size_t* bytes);

@@ -523,7 +523,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                             u32x4_t qd = __builtin_bit_cast(u32x4_t, q);
                             asm volatile("" : "+v"(qd));
                             __builtin_amdgcn_raw_buffer_store_b128(qd, rs_out16, off[j0 + jj][it], 0, 0);
-                            asm volatile("s_nop 1" :: "v"(qd) : "memory");     // store data stays untouched behind the store
+                            asm volatile("s_nop 1" :: "v"(qd) : "memory");     // store data stays untouched behind the store (NOTES/design_history_r1_r5.md §9.1)
                         }
                     }
                 }
@@ -635,7 +635,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const unsigned w)
                                 __builtin_amdgcn_raw_buffer_store_b64(t0, rs_tw, toff, 0, 0);
                                 __builtin_amdgcn_raw_buffer_store_b64(t1, rs_tw, toff, 32, 0);
                                 __builtin_amdgcn_raw_buffer_store_b128(ov, rs_out, o, 0, 0);
-                                asm volatile("s_nop 3" :: "v"(t0), "v"(t1), "v"(ov) : "memory");     // store data stays untouched behind the stores
+                                asm volatile("s_nop 3" :: "v"(t0), "v"(t1), "v"(ov) : "memory");     // store data stays untouched behind the stores (NOTES/design_history_r1_r5.md §9.1)
                                 continue;
                             }
                         }

@@ -10,7 +10,7 @@
 // showed 216 of them take 4.1k clk per wave where 108 of the 32x32x16 take 3.5k -- MI355X_MICROARCH.md: 2075 vs 2382 TF).
 //
 // Why another kernel.  The generic kernel stages a chunk (54 KB of weights + the halo tile), waits, multiplies, and
-// relies on a second resident workgroup to fill the wait.  Measured: the two workgroups drift into
+// relies on a second resident workgroup to fill the wait.  Measured (NOTES/design_history_r1_r5.md §4): the two workgroups drift into
 // phase, the LDS-DMA issue of one (~100 clk per 1 KB piece on the issuing wave) lands on top of its own MFMA phase
 // as often as under the other's, and the MFMA pipe is busy 40 % of the kernel although the work is MFMA-bound.
 // Here the alternation is BUILT IN:

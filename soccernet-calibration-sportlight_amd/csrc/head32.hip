@@ -344,7 +344,7 @@ bool launch_head32(const HeadParams& p, hipStream_t s) {
         return finish_trace(q, n_tr, trace_file, s);
     }
     // SNCAL_HEAD_HILO=1 (experiment): stage 2 multiplies the hidden vector as bf16 hi + bf16 lo (16 mantissa
-    // bits instead of 8) -- what "hidden -> logits in higher precision" buys is measured with tests/test_parity_gpu.py, DESIGN.md 8
+    // bits instead of 8) -- what "hidden -> logits in higher precision" buys is measured with tests/test_parity_gpu.py, NOTES/design_history_r1_r5.md §8
     static const int hilo = getenv("SNCAL_HEAD_HILO") ? atoi(getenv("SNCAL_HEAD_HILO")) : 0;
     if (rb == 2) {
         if (hilo) SNCAL_LAUNCH((head32_kernel<2, 13, 1, 1, 0>), dim3(blocks), dim3(256), 2 * lds1, s, q);

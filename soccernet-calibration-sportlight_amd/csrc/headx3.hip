@@ -7,7 +7,7 @@
 //              VALU     h = relu(h)                 (the folded-BN shift is stage 1's initial value), fp32
 //     stage 2  MFMA x3  logits += W1[:, 32-slice] . h
 // Every product a.b of two fp32 operands is a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_bf16 with hi = bf16(x),
-// lo = bf16(x - hi) (2^-17 per operand), accumulated in fp32: the arithmetic of conv_tt's MODE 2.  The weights arrive
+// lo = bf16(x - hi) (2^-17 per operand), accumulated in fp32: the arithmetic of conv_tt's MODE 2 (NOTES/design_history_r1_r5.md §9.3).  The weights arrive
 // split from the host (hi and lo A fragments side by side in the slice), activations are split in registers: the direct tensor and the
 // bilinear blends of the folded branches once per tile (26 B fragments), the gathered box pixels and the hidden vector per slice.
 // Why: in the fp32-class engines the head was three passes over fp32 tensors of 784 channels x 270 x 480 x 64 frames = 26 GB each

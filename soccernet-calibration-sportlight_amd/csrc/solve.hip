@@ -789,7 +789,7 @@ __device__ void pose_normal_eq(u64 mask, const double* x, const K4& k, const dou
 // multiply -- 6 reciprocal square roots per factorisation and no division in a solve, where chol_solve's form has 6 square roots + 15
 // divisions per factorisation and 12 dependent divisions per solve.  refine_camera's slow fits (20000 iterations at the reference's
 // criterion, camera.py:116) are ONE wavefront issuing ~2200 dependent fp64 instructions per iteration: 7.8 us each, 160 ms for the fit that
-// sets the latency of a batch's solve; a fifth of those instructions were divisions.  Same pivot rule as sym_factor6 (a
+// sets the latency of a batch's solve (NOTES/design_history_r1_r5.md §11.1); a fifth of those instructions were divisions.  Same pivot rule as sym_factor6 (a
 // failing pivot sends the caller to its eigen-decomposition fallback); results differ from the dividing form by rounding only.
 struct Chol6 { double L[6][6]; double rinv[6]; bool ok; };
 __device__ __forceinline__ void chol6_factor(const double (&A)[6][6], Chol6& F) {

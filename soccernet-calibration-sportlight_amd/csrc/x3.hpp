@@ -1,5 +1,5 @@
 // The 16-bit type of the split (x3) arithmetic: every fp32 operand x = hi + lo, hi = rne16(x), lo = rne16(x - hi), every product
-// w.x = w_hi.x_hi + w_hi.x_lo + w_lo.x_hi on the 16-bit matrix pipe with fp32 accumulation.
+// w.x = w_hi.x_hi + w_hi.x_lo + w_lo.x_hi on the 16-bit matrix pipe with fp32 accumulation (NOTES/design_history_r1_r5.md §9.3 / 10).
 //   SNCAL_X3_F16 = 1 (default since round 4): hi and lo are IEEE fp16 -- 11 + 11 significand bits, the dropped lo.lo term is ~2^-22 of a
 //     product; v_mfma_*_f16 keeps fp16 subnormals and accumulates exactly (tools/dev/f16_mfma_probe.hip), so small operands lose
 //     precision gracefully (|x| < 2^-3: lo is subnormal, absolute error <= 2^-25) and nothing needs scaling; |x| is clamped to the

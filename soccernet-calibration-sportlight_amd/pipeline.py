@@ -11,7 +11,7 @@ stream and the step grows from 43 to 54 ms.  Export GPU_MAX_HW_QUEUES=8 before t
 
 Round 5 -- the solves at the REFERENCE's refine criterion (baseline/camera.py:116: solvePnPRefineLM (20000, 1e-5)).
 One crawling Levenberg-Marquardt fit keeps a single wavefront busy for up to ~330 ms, and a launch ends with its
-slowest wavefront.  Three things follow (all measured):
+slowest wavefront.  Three things follow (NOTES/design_history_r1_r5.md §11.1, all measured):
 
 * A POOL of solve streams: batch k goes to solve stream k mod P (P = SOLVE_STREAMS, default 3 -- see below why not
   more --, shared by every pipeline of a device), so up to P batches are being solved while the network runs on; on ONE side stream the

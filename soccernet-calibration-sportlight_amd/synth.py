@@ -264,6 +264,71 @@ def deep_state_dict(sd: dict, peak_logit: float = 12.0, noise_gain: float = 0.25
     return out
 
 
+def line_keypoints():
+    """{line class index (LINE_CLS order): [keypoint ids that lie on it]} from the 30 line-pair intersections the reference joins
+    (LINE_INTERSECTIONS, prediction.py:105-124)."""
+    from .lines import LINE_CLS, LINE_INTERSECTIONS
+    index = {name: i for i, name in LINE_CLS.items()}
+    on = {i: [] for i in LINE_CLS}
+    for kp, pair in LINE_INTERSECTIONS.items():
+        for name in pair:
+            on[index[name]].append(int(kp))
+    return on
+
+
+def line_deep_state_dict(sd_line: dict, peak_logit: float = 12.0, noise_gain: float = 0.25, amp: float = 48.0, a1: float = 0.5,
+                         a2: float = -0.04, fuse_gain: float = 0.1, cut: float = 0.25, boost: float = 3.0, row_gain: float = 0.1) -> dict:
+    """The C4 workload's LINE network (BASELINE config C4; src/models/line/hrnet.py: the W48 backbone, no stem concat, Softmax over the 23
+    line classes at stride 4): random-init `sd_line` with the SAME deep signal path as the keypoint network's (deep_state_dict: keypoint
+    class k rides channel k of every backbone tensor -- the frames carry the keypoint stamps, both networks see the same frames) and a
+    head that answers with LINES: hidden k reads channel k of the upsampled branches, the logit of line l sums the hidden units of the
+    keypoints that lie on l (line_keypoints).  At a visible keypoint the two lines that cross there get ~peak_logit each (softmax 0.5 /
+    0.5), elsewhere all 23 logits are the random network's noise (~1/23 each): the two-peak decode (EHMPredictionTransform) finds two
+    keypoints of every line that shows two, get_line_data (prob_thre 0.2, its own default) drops the others, and the line-pair
+    intersections land on the keypoints the keypoint network decodes -- line points CONSISTENT with the frame, as a trained line network
+    gives.  (The round 2-5 C4 bench used the raw random line network: 28 garbage line points per frame, 21 of them inside the image, which
+    original_voter adds to every frame's point set (prediction.py:356-364); two frames in three then failed the first pass and every
+    candidate fit crawled to 20000 iterations -- a solve stage of 320 ms per batch on the masked CUs, profiles/README.md round 6.)"""
+    import torch
+    tmp = {k: v.clone() for k, v in sd_line.items()}
+    # deep_state_dict installs the backbone path and writes a keypoint-shaped head: give it scratch head tensors, keep its backbone
+    for key, shape in (('model.last_layer.0.weight', (784, 784, 1, 1)), ('model.last_layer.0.bias', (784,)), ('model.last_layer.1.weight', (784,)),
+                       ('model.last_layer.1.bias', (784,)), ('model.last_layer.1.running_mean', (784,)), ('model.last_layer.1.running_var', (784,)),
+                       ('model.last_layer.3.weight', (58, 784, 1, 1)), ('model.last_layer.3.bias', (58,))):
+        tmp[key] = torch.ones(shape) if key.endswith('running_var') else torch.zeros(shape)
+    deep = deep_state_dict(tmp, peak_logit=peak_logit, noise_gain=noise_gain, amp=amp, a1=a1, a2=a2, fuse_gain=fuse_gain, cut=cut, boost=boost,
+                           row_gain=row_gain)
+    out = {k: (sd_line[k].clone() if k.startswith('model.last_layer.') else deep[k]) for k in sd_line}
+    widths = {}
+    for key, v in out.items():
+        if key.startswith('model.stage4.0.branches.') and key.endswith('.0.conv1.weight'):
+            widths[int(key.split('.')[4])] = v.shape[0]
+    eps = 1e-5
+    w0 = out['model.last_layer.0.weight']                  # (720,720,1,1); concat order b0 | b1 | b2 | b3 (no stem: upscale 1)
+    w0[:57] = 0.0
+    off = 0
+    for b in sorted(widths):
+        n = min(57, widths[b])
+        idx = torch.arange(n)
+        w0[idx, off + idx, 0, 0] = 1.0
+        off += widths[b]
+    for key, val in (('weight', 1.0), ('bias', 0.0), ('running_mean', 0.0), ('running_var', 1.0 - eps)):
+        out[f'model.last_layer.1.{key}'][:57] = val
+    peaks = {True: _signal_peak(True, amp, a1 * a2, fuse_gain), False: boost * _signal_peak(False, amp, a1 * a2, fuse_gain)}
+    w1 = out['model.last_layer.3.weight']                  # (23,720,1,1)
+    w1 *= noise_gain
+    w1[:, :57] = 0.0
+    out['model.last_layer.3.bias'] *= noise_gain
+    on = line_keypoints()
+    for k in range(57):
+        pk = peaks[k < widths[0]]
+        out['model.last_layer.0.bias'][k] = -cut * pk
+        for line, kps in on.items():
+            if k in kps:
+                w1[line, k, 0, 0] = peak_logit / ((1.0 - cut) * pk)
+    return out
+
+
 def stamped_frames(n: int, seed: int = 0, sigma_cells: float = 2.0, jitter_px: float = 1.0, min_visible: int = 8,
                    size=(540, 960)):
     """(frames (n,3,H,W) float32 in [0,1] -- uniform-noise background in [0.25, 0.75) with the keypoint stamps --, expect (n,57,3) float32

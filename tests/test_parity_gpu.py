@@ -7,7 +7,7 @@ the head through the upsampled branch channels only, so the position of a heatma
 north_star: "bit-identical keypoint indices on the same frames", "within 1e-4 relative on reprojection error".  The fp32 engine is
 the one pinned to the reference capture (tests/test_hrnet_gpu.py) and kernel by kernel to torch fp32 (tests/test_kernels_gpu.py);
 this file MEASURES how far the bf16 / fp8 engines are from it, at three noise settings and 16 frames, on all frames:
-the tables go to gpurun_out/ (-> profiles/) and decide load_model's default dtype (DESIGN.md 5).
+the tables go to gpurun_out/ (-> profiles/) and decide load_model's default dtype (DESIGN.md §5).
 Solve parity is against the build's own oracle only -- OpenCV parity unpinned.
 """
 import json

@@ -1,6 +1,6 @@
 """GPU: the HIP camera solve against scipy.optimize.least_squares DIRECTLY -- an author-independent check.
 
-OpenCV parity of the solve is unpinned (cv2 4.7.0.72 is not installable offline; DESIGN.md 2), and `tests/test_solve_gpu.py` compares
+OpenCV parity of the solve is unpinned (cv2 4.7.0.72 is not installable offline; DESIGN.md §2), and `tests/test_solve_gpu.py` compares
 the kernels with `oracle/solve.py`: two implementations of one recalled specification by one author.  This module never imports
 `oracle/`: residuals are written here from the reference's own definition of the quantities (pinhole projection with
 K = diag(f, f, 1) + principal point, X_cam = R (X - position): baseline/camera.py:249-277 `project_point`; the three minimisations are

@@ -1,4 +1,4 @@
-// Dev probe for the fp16-split engine: what v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 do on gfx950 with
+// Dev probe for the fp16-split engine (NOTES/design_history_r1_r5.md §10): what v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 do on gfx950 with
 //   (a) fp16 SUBNORMAL inputs (lo = fp16(x - fp16(x)) is subnormal for |x| < 2^-3): kept or flushed?
 //   (b) products whose exact value needs 22 significand bits: summed exactly into the fp32 accumulator or truncated on the way
 //       (the MX fp8 instruction truncates 2^-13 below the largest product of a group: tools/dev/fp8_acc_probe.hip)?

@@ -1,4 +1,4 @@
-// Dev probe behind DESIGN.md 9.3: a v_mfma_f32_16x16x16_bf16 that takes as SrcC the vDst of the v_mfma_f32_16x16x32_bf16 issued right
+// Dev probe behind NOTES/design_history_r1_r5.md §9.3: a v_mfma_f32_16x16x16_bf16 that takes as SrcC the vDst of the v_mfma_f32_16x16x32_bf16 issued right
 // before it (hipcc 7.2 emits the pair without wait states), with identical and with half-overlapping vDst / SrcC registers, against the
 // same arithmetic with s_nop 15 between the two instructions.  Prints how many of the 256 accumulator elements differ.
 //   hipcc --offload-arch=gfx950 -O2 tools/dev/mfma_pair_probe.hip -o /tmp/mfma_pair_probe && /tmp/mfma_pair_probe

@@ -1,4 +1,4 @@
-"""PCIe-inclusive rate (DESIGN.md 5): frames start in PINNED HOST memory as cv2-style uint8 (B,540,960,3); every step
+"""PCIe-inclusive rate (DESIGN.md §5): frames start in PINNED HOST memory as cv2-style uint8 (B,540,960,3); every step
 uploads its batch on a copy stream (double-buffered) and runs the whole pipeline (forward_u8 + decode + solves).
 Also the JPEG variant: encoded frames in host memory -> JpegDecoder (host Huffman threads + device kernels) -> pipeline."""
 import os, sys, time

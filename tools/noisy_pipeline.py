@@ -1,6 +1,6 @@
 """What the camera solves cost the step at the REFERENCE's refine criterion (baseline/camera.py:116: (20000, 1e-5), the library default)
 when the frames are hard: N noisy synthetic keypoint frames (noise 0.5 / 1 / 2 / 4 px in turn; the 4-px ones hold the slow
-Levenberg-Marquardt fits: mean 121 ms, worst 320 ms per batch of 64 on ONE stream) ride through the bench's own step as
+Levenberg-Marquardt fits: mean 121 ms, worst 320 ms per batch of 64 on ONE stream, NOTES/design_history_r1_r5.md §10.10) ride through the bench's own step as
 `extra_keypoints` -- every step = HRNet-W48 960x540 forward + decode of 64 frames + the solve of 64 noisy frames IN PLACE of the decoded
 ones (`solve_decoded=False`: one solve per step, as in production; `both` adds the decoded keypoints' solve on top) -- and the step time is
 set against the same steps without any solve.  VERDICT r4 item 1: within 3 %.  Reported: the whole run (with the pipeline's drain: the

@@ -17,7 +17,7 @@ def label(k):
             else 'bblock48_fused' if 'bblock48_kernel' in k else k)
 # Read correction per kernel: FETCH_SIZE x 1 KB reports HALF of a wide coalesced read stream on gfx950 (x2, the guide's correction), but
 # ALL of the bytes of isolated 64-byte pieces 1600 B apart and 3/4 of 128-byte pieces at that stride (tools/dev/fetch_probe.hip,
-# DESIGN 9.6 item 7).  The fused heads read their gather boxes in exactly such pieces (plus one coalesced stream, the stem tensor):
+# NOTES/design_history_r1_r5.md §9.6 item 7).  The fused heads read their gather boxes in exactly such pieces (plus one coalesced stream, the stem tensor):
 # the measured mix is ~1.3; every other kernel reads coalesced streams (LDS-DMA halo rows, weight fragments, fp32 rows).
 # The stem's second convolution (64 -> 64, stride 2, fp32 rows of 256 B per pixel): x2 gives 7.23 GB per 865 us launch = 8.4 TB/s, more than the
 # HBM can deliver -- for that stream the counter evidently reports the bytes in full; x1 (3.9 GB, 1.5 x its 2.6 GB of

@@ -1327,7 +1327,7 @@ void tt_member(const sncal_hrnet& net, const Op& op, int sb, char* ws, TTMember&
 // (longest-processing-time order: the teams, which take the next item when they finish one, end within one cheap item
 // of each other).  Rounds 2-4 dealt the items to the teams HERE (static lists); a workgroup whose CU was held by a
 // camera-solve wavefront then started when the first other workgroup had finished, and the launch lasted twice as long.
-int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, int tile_h = TT_TH, int cout_blk = TT_COUT) {
+int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTPlanDev& out, hipStream_t stream, int tile_h = TT_TH, int cout_blk = TT_COUT) {
     if (!net.n_cus) {
         int dev = 0, cus = 0;
         SNCAL_CHECK_HIP(hipGetDevice(&dev));
@@ -1366,8 +1366,11 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     if (flat.empty()) flat.push_back(TTItem{0, 0, 0, 0, 0});
     SNCAL_CHECK_HIP(hipMalloc((void**)&out.items, flat.size() * sizeof(TTItem)));
     SNCAL_CHECK_HIP(hipMalloc((void**)&out.first, first.size() * 4));
-    SNCAL_CHECK_HIP(hipMemcpy(out.items, flat.data(), flat.size() * sizeof(TTItem), hipMemcpyHostToDevice));
-    SNCAL_CHECK_HIP(hipMemcpy(out.first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    // on the forward's OWN stream, then a wait for that stream only: a plain hipMemcpy runs on the legacy null stream, which synchronises with
+    // the pipeline's CU-masked (blocking) solve streams -- a new layout (the tail batch of a directory) then waited for every solve in flight
+    SNCAL_CHECK_HIP(hipMemcpyAsync(out.items, flat.data(), flat.size() * sizeof(TTItem), hipMemcpyHostToDevice, stream));
+    SNCAL_CHECK_HIP(hipMemcpyAsync(out.first, first.data(), first.size() * 4, hipMemcpyHostToDevice, stream));
+    SNCAL_CHECK_HIP(hipStreamSynchronize(stream));       // (the host vectors die here; once per layout)
     out.n_wgs = n_wgs;
     // fewer than 8 pairs of items per workgroup in an XCD's list: the kernel's three-pairs-ahead ticket pipeline would starve most workgroups
     out.lazy = flat.size() < (size_t)3 * (size_t)n_wgs ? 1 : 0;      // fewer than 1.5 pairs per workgroup
@@ -1426,7 +1429,7 @@ int run_conv_tt(sncal_hrnet& net, const Op* ops, int n, int key, int sb, char* w
             if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; }
             if (items < (long)per_team * 2 * cus) { tile_h = 4; pd.cfg = 2; }
         }
-        const int rc = tt_build_plan(net, tp.m, n, pd, tile_h, cfg64 ? 64 : TT_COUT);
+        const int rc = tt_build_plan(net, tp.m, n, pd, stream, tile_h, cfg64 ? 64 : TT_COUT);
         if (rc) return rc;
         it = net.tt_plans.insert({key, pd}).first;
     }

@@ -188,3 +188,36 @@ def test_opencv_calibration_returns_scipys_joint_minimum(seed):
     assert abs(_mean_l2(r_hip) - _mean_l2(sp.fun)) <= 1e-4 * _mean_l2(sp.fun), (_mean_l2(r_hip), _mean_l2(sp.fun))
     assert abs(rec.fx - sp.x[0]) <= 1e-3 * sp.x[0]                       # CvLevMarq stops after 30 iterations: f to 1e-3, the error to 1e-4
     assert abs(rec.fx - cam['f']) < 0.05 * cam['f']
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_iterative_voter_camera_is_a_pose_minimum_under_its_own_calibration(seed):
+    """The bench's algorithm end to end (CameraCreator 'iterative_voter' with make_submit.py:45-50's parameters; prediction.py:245-257,
+    339-437): whatever route produced the camera, its last step is Camera.refine_camera over the matched points with the calibration
+    matrix the record carries (fx, fy, cx, cy -- the principal point calibrateCamera fixed at ((w - 1) / 2, (h - 1) / 2), quirk Q3), so
+    the returned pose must be scipy's minimum of THAT residual, and the record's rmse must be the mean L2 the reference's
+    projection_rmse reports (principal point (w / 2, h / 2), baseline/camera.py:249-277)."""
+    import sncal_amd
+    W = _world()
+    (cam, ids, obs), = _frames(1, 500 + seed, sigma=0.7, min_visible=14)
+    kp = np.zeros((1, 57, 3), dtype=np.float32)
+    kp[0, ids, :2] = obs
+    kp[0, ids, 2] = 0.9
+    cc = sncal_amd.CameraCreator(sncal_amd.PITCH_POINTS, conf_thresh=0.5, conf_threshs=[0.5, 0.35, 0.2], algorithm='iterative_voter',
+                                 max_rmse=55.0, max_rmse_rel=5.0, min_points=5, min_focal_length=10.0, min_points_per_plane=6,
+                                 min_points_for_refinement=6, reliable_thresh=57)
+    rec = cc.records(cc.solve_device(torch.from_numpy(kp).cuda()))[0]
+    assert rec.status == 1, rec.status                                   # the first pass's calibrated camera (clean frame)
+    X, o = W[ids], kp[0, ids, :2].astype(np.float64)
+    R = np.array(rec.rotation[:]).reshape(3, 3)
+    pos = np.array(rec.position[:])
+    res = _pose_residual(rec.fx, rec.cx, rec.cy, X, o, R)
+    x0 = np.r_[0, 0, 0, -R @ pos]
+    sp = _lm(res, x0)
+    r_hip = res(x0)
+    assert float(r_hip @ r_hip) <= 2 * sp.cost * (1 + 1e-6), (float(r_hip @ r_hip), 2 * sp.cost)
+    assert abs(_mean_l2(r_hip) - _mean_l2(sp.fun)) <= 1e-4 * _mean_l2(sp.fun)
+    uv, _ = _project(rec.fx, 480.0, 270.0, R, -R @ pos, X)              # what the record's rmse is measured with
+    # (the reference's project_point rounds the normalised coordinates to float32, quirk mirrored by the kernel: ~1e-4 px at f = 4000)
+    assert abs(rec.rmse - float(np.linalg.norm(uv - o, axis=1).mean())) <= 5e-4
+    assert abs(rec.fx - cam['f']) < 0.05 * cam['f'] and np.linalg.norm(pos - cam['pos']) < 3.0

@@ -776,6 +776,9 @@ __global__ __launch_bounds__(256, conv_launch_wgs<T>(3, NI, 6, G)) void conv_sha
     else conv_body<T, 3, 2, NI, 3, G>(q, w);
 }
 void launch_conv_shared_s2_x3(const ConvSharedParams& sp, unsigned blocks, size_t lds, hipStream_t s);      // conv_x3.hip: x3_t, NI 2, G 3
+// conv_s2p.hip: the same work (one to three stride-2 convolutions on one input; a single convolution = one member) on the pipelined
+// persistent kernel; ticket = nine zeroed device words of the caller's stream
+int launch_conv_s2p_x3(const ConvSharedParams& sp, unsigned* ticket, hipStream_t s);
 
 // host-visible launcher table ---------------------------------------------------------------------
 typedef void (*ConvLaunchFn)(const ConvParams&, dim3 grid, size_t lds, hipStream_t s);

@@ -126,6 +126,7 @@ struct sncal_hrnet {
     bool split_enabled = getenv("SNCAL_SPLIT_HEAD") ? atoi(getenv("SNCAL_SPLIT_HEAD")) != 0 : true, use_split = false;
     // wide 3x3 stride-1 convolutions (96 / 192 / 384 channels) on the two-team persistent kernel (conv_tt.hip), bf16 path
     bool use_conv_tt = getenv("SNCAL_CONV_TT") ? atoi(getenv("SNCAL_CONV_TT")) != 0 : true;
+    bool use_s2p = getenv("SNCAL_S2P") ? atoi(getenv("SNCAL_S2P")) != 0 : false;     // fp16x3: 3x3 stride-2 convolutions on the pipelined persistent kernel (conv_s2p.hip): bit-identical, measured slower -> off
     struct TTPlanDev { sncal::TTItem* items = nullptr; uint32_t* first = nullptr; int n_wgs = 0; int lazy = 0; int cfg = 0; };
     std::map<int, TTPlanDev> tt_plans;    // work lists per launch (key: index of its first op), rebuilt when the layout changes
     int n_cus = 0;
@@ -1377,10 +1378,13 @@ int tt_build_plan(sncal_hrnet& net, const TTMember* mem, int n, sncal_hrnet::TTP
     return SNCAL_OK;
 }
 
+// ticket words of a network: [0, 9) and [16, 25) the fused blocks, [32, 48) the two-team kernel, [48, 57) layer1's seams, [64, 73) the
+// pipelined stride-2 kernel
+constexpr int TICKET_WORDS = 96;
 static int ensure_tickets(sncal_hrnet* net, hipStream_t stream) {
     if (net->d_tickets) return SNCAL_OK;
-    SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_tickets), 64 * sizeof(unsigned)));
-    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, 64 * sizeof(unsigned), stream));
+    SNCAL_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_tickets), TICKET_WORDS * sizeof(unsigned)));
+    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, TICKET_WORDS * sizeof(unsigned), stream));
     return SNCAL_OK;
 }
 
@@ -1506,6 +1510,23 @@ int run_conv(sncal_hrnet& net, const Op& op, int sb, char* ws, hipStream_t strea
         n_trace = (size_t)8 * ((p.n_work + 7) / 8) * 16;
         if (hipMalloc(&d_trace, n_trace * 8) == hipSuccess) { (void)hipMemsetAsync(d_trace, 0, n_trace * 8, stream); p.trace = d_trace; }
     }
+    const bool s2p = net.x3_generic && net.use_s2p && !d_trace && !p.ablate && bestv->ks == 3 && bestv->stride == 2 && bestv->ni == 2 && bestv->g == 3 &&
+                     (bestv->mi == 6 || bestv->mi == 3);
+    if (s2p) {               // the one-member case of the pipelined stride-2 kernel
+        ConvSharedParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.p[0] = p; sp.mi[0] = bestv->mi;
+        sp.first[0] = 0;
+        for (int i = 1; i < 4; ++i) sp.first[i] = (unsigned)p.nblk;
+        sp.n = 1;
+        sp.tiles = (unsigned)(p.tiles_x * p.tiles_y * sb);
+        sp.tiles_per_xcd = (sp.tiles + 7) / 8;
+        { const int rc2 = ensure_tickets(&net, stream); if (rc2) return rc2; }
+        const int rc2 = launch_conv_s2p_x3(sp, net.d_tickets + 64, stream);
+        if (rc2) return rc2;
+        if (net.profiling) { conv_profile_entry(net, op, sb, bestv, false); static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr; if (!detail) net.last_kernel = "conv_s2p<" SNCAL_X3_NAME ",k3,s2>"; }
+        return SNCAL_OK;
+    }
     bestv->launch(p, dim3(8 * p.per_xcd), best_lds, stream);
     SNCAL_CHECK_LAUNCH();
     if (d_trace) {
@@ -1574,14 +1595,20 @@ int run_conv_group(sncal_hrnet& net, const Op* ops, int n, int sb, char* ws, hip
         sp.n = n;
         sp.tiles = (unsigned)(sp.p[0].tiles_x * sp.p[0].tiles_y * sb);
         sp.tiles_per_xcd = (sp.tiles + 7) / 8;
-        launch_conv_shared_s2_x3(sp, 8u * sp.tiles_per_xcd * ipt, lds_s, stream);
-        SNCAL_CHECK_LAUNCH();
+        if (net.use_s2p && !sp.p[0].ablate) {
+            { const int rc2 = ensure_tickets(&net, stream); if (rc2) return rc2; }
+            const int rc2 = launch_conv_s2p_x3(sp, net.d_tickets + 64, stream);
+            if (rc2) return rc2;
+        } else {
+            launch_conv_shared_s2_x3(sp, 8u * sp.tiles_per_xcd * ipt, lds_s, stream);
+            SNCAL_CHECK_LAUNCH();
+        }
         if (net.profiling) {
             for (int i = 0; i < n; ++i) conv_profile_entry(net, ops[i], sb, vs[i], i > 0);
             const Tensor& ti = net.tensors[ops[0].in];
             net.last_bytes -= (double)(n - 1) * sb * ti.H * ti.W * ti.C * net.esize;      // the members' common input counts once
             static const bool detail = getenv("SNCAL_PROFILE_DETAIL") != nullptr;
-            if (!detail) net.last_kernel = "conv_shared_s2<" SNCAL_X3_NAME ",k3,NI2,G3>";     // (its own row: not the first member's variant)
+            if (!detail) net.last_kernel = net.use_s2p ? "conv_s2p_shared<" SNCAL_X3_NAME ",k3,s2>" : "conv_shared_s2<" SNCAL_X3_NAME ",k3,NI2,G3>";     // (its own row: not the first member's variant)
         }
         *done = true;
         return SNCAL_OK;
@@ -2101,7 +2128,7 @@ extern "C" int sncal_hrnet_plan_tap(sncal_hrnet* net, int op_idx, int tensor_id,
 static int rearm_tickets(sncal_hrnet* net, hipStream_t stream) {
     const int rc = ensure_tickets(net, stream);
     if (rc) return rc;
-    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, 64 * sizeof(unsigned), stream));
+    SNCAL_CHECK_HIP(hipMemsetAsync(net->d_tickets, 0, TICKET_WORDS * sizeof(unsigned), stream));
     return SNCAL_OK;
 }
 

@@ -563,6 +563,17 @@ def test_every_launch_of_the_fp16x3_engine_w48_540p(sncal, cuda, monkeypatch, sm
     assert n('bneck_tail_ds_x3') == 1 and n('bneck_seam_x3') == 4, {k: v.get('ops') for k, v in stats.items()}
 
 
+def test_every_launch_of_the_fp16x3_engine_with_the_pipelined_stride2_kernel(sncal, cuda, monkeypatch):
+    """SNCAL_S2P=1: the 3x3 stride-2 convolutions (transitions and fuse-down chains, hrnet.py:183-214, 357-391) on the pipelined
+    persistent kernel (conv_s2p.hip; parked: measured slower than the generic kernel, off by default) -- every launch against torch fp32
+    like the default path, at W48 540p (96- and 48-channel n-blocks, shared launches) and W32 270p."""
+    monkeypatch.setenv('SNCAL_S2P', '1')
+    stats = verify_plan(sncal, cuda, 'hrnet_w48', _weights('hrnet_w48'), _frames(3, 540, 960, 18, cuda), 'fp16x3', tag='w48 540p fp16x3 s2p')
+    n = lambda key: sum(v.get('ops', 0) for k, v in stats.items() if k.startswith(key))
+    assert n('conv_s2p<') >= 20 and n('conv_s2p_shared<') >= 20, {k: v.get('ops') for k, v in stats.items()}
+    verify_plan(sncal, cuda, 'hrnet_w32', _weights('hrnet_w32'), _frames(2, 270, 480, 19, cuda), 'fp16x3', tag='w32 270p fp16x3 s2p')     # (whichever of its stride-2 layers pack at G = 3)
+
+
 def test_every_launch_of_the_fp16x3_engine_w32_270p(sncal, cuda):
     """BASELINE config C2's shapes (HRNet-W32, 480x270): branch widths 32 / 64 / 128 / 256 all run as 64-channel blocks of the
     64 x 12 x 32 tile (the 32-channel branch half padded), maps 68x120 / 34x60 / 17x30 / 9x15 (a 9-row branch inside 12-row tiles)."""

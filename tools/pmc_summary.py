@@ -7,7 +7,9 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         m = re.search(r'conv_(?:group_)?kernelI(\w+?)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E', k)
-        if 'conv_shared_s2_kernel' in k:
+        if 'conv_s2p_kernel' in k:
+            k, m = 'conv_s2p<fp16x3,k3,s2>', None
+        elif 'conv_shared_s2_kernel' in k:
             k, m = 'conv_shared_s2<fp16x3,k3,NI2,G3>', None
         elif 'conv_tt_kernel' in k:
             mode = 'fp8' if ('ILb1' in k or '<true>' in k or 'ILi1E' in k or 'kernel<1>' in k) else 'fp16x3' if ('ILi2E' in k or 'kernel<2>' in k) else 'bf16'

@@ -29,6 +29,7 @@ slowest wavefront.  Three things follow (NOTES/design_history_r1_r5.md §11.1, a
   (`with pipe.stream():` provides one; bench.py and submit.py do); a caller on the null stream gets plain
   non-blocking solve streams -- correct, ordered by the same events, but paying the scattered-CU price above.
 """
+import atexit
 import contextlib
 import os
 
@@ -88,6 +89,24 @@ def _solve_pool(device, masked):
                     streams.append(torch.cuda.Stream(device=idx))
         _POOLS[key] = [streams, 0, masked]
     return _POOLS[key]
+
+
+def _destroy_masked_pools():
+    """At interpreter exit: the CU-masked solve streams are created by the library (hipExtStreamCreateWithCUMask), torch only borrows
+    them (ExternalStream) -- nobody else destroys them, and a process that exits with such streams alive crashed in a library finaliser
+    under rocprofv3 (SIGSEGV inside __cxa_finalize after the tool's output was written; unmasked pools did not).  sncal_stream_destroy
+    also releases the scratch block sncal_calibrate may hold for the stream."""
+    for key in [k for k in _POOLS if k[1]]:
+        streams = _POOLS.pop(key)[0]
+        for s in streams:
+            try:
+                s.synchronize()
+                _lib.lib().sncal_stream_destroy(s.cuda_stream)
+            except Exception:
+                pass
+
+
+atexit.register(_destroy_masked_pools)
 
 
 class CalibrationPipeline:

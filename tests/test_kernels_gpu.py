@@ -570,7 +570,7 @@ def test_every_launch_of_the_fp16x3_engine_with_the_pipelined_stride2_kernel(snc
     monkeypatch.setenv('SNCAL_S2P', '1')
     stats = verify_plan(sncal, cuda, 'hrnet_w48', _weights('hrnet_w48'), _frames(3, 540, 960, 18, cuda), 'fp16x3', tag='w48 540p fp16x3 s2p')
     n = lambda key: sum(v.get('ops', 0) for k, v in stats.items() if k.startswith(key))
-    assert n('conv_s2p<') >= 20 and n('conv_s2p_shared<') >= 20, {k: v.get('ops') for k, v in stats.items()}
+    assert n('conv_s2p<') >= 20 and n('conv_s2p_shared<') >= 8, {k: v.get('ops') for k, v in stats.items()}      # (members of a shared launch carry the first member's label)
     verify_plan(sncal, cuda, 'hrnet_w32', _weights('hrnet_w32'), _frames(2, 270, 480, 19, cuda), 'fp16x3', tag='w32 270p fp16x3 s2p')     # (whichever of its stride-2 layers pack at G = 3)
 
 

@@ -17,7 +17,8 @@ cp profiles/pmc_traffic.json profiles/${tag}_pmc_hbm_traffic.md profiles/${tag}_
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err      # the driver's command
 timeout 900 python tools/noisy_pipeline.py 2048 $O/noisy_pipeline_2048.json > /dev/null 2>&1
 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_c3_bf16.json 2> $O/bench_c3_bf16.err
-python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --workload c4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --workload c4 --line-workload random --no-cpu-baseline --no-parity > $O/bench_c4_random_lines.json 2> $O/bench_c4_random_lines.err
 python bench.py --dtype fp8 --no-cpu-baseline > $O/bench_c3_fp8.json 2> $O/bench_c3_fp8.err
 python bench.py --dtype fp8 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_fp8.json 2> $O/bench_c5_fp8.err
 python bench.py --dtype bf16 --size 1080p --batch 64 --no-cpu-baseline > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err

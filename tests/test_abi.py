@@ -215,6 +215,12 @@ def test_argument_validation_and_empty_batches_without_a_gpu():
     assert lib.sncal_line_decode(None, 0, 23, 135, 240, 3.0, 4.0, None, None) == 0
     assert lib.sncal_lines_to_points(None, 0, 4.0, 0.0, None, None) == 0
     assert lib.sncal_calibrate(None, None, 0, ctypes.byref(cfg), None, None) == 0
+    assert lib.sncal_calibrate_ws(None, None, 0, ctypes.byref(cfg), None, None, 0, None) == 0
+    n1, n64 = ctypes.c_size_t(), ctypes.c_size_t()                      # the solve's caller-owned workspace: a host-only size query
+    assert lib.sncal_calibrate_workspace(1, ctypes.byref(cfg), ctypes.byref(n1)) == 0 and lib.sncal_calibrate_workspace(64, ctypes.byref(cfg), ctypes.byref(n64)) == 0
+    assert 256 <= n1.value < n64.value <= 64 * 3 * 2048 + 64 * 1024
+    assert lib.sncal_calibrate_workspace(64, None, ctypes.byref(n64)) == ERR_ARG
+    assert lib.sncal_shutdown() == 0                                    # nothing held: a no-op that must not need a GPU
     assert lib.sncal_create_target(None, 0, 57, 3.0, 270, 480, None, None) == 0
     assert lib.sncal_evaluate_cameras(None, 0, None, None, None, 26, None, None, None, 4, 5.0, 960, 540, None, None) == 0
     # bad shapes / null pointers

@@ -13,7 +13,7 @@
 // CU's second workgroup to multiply meanwhile, and the two drift into phase.  The class's loss is OVERLAP, not bandwidth.
 //
 // Here one workgroup per CU runs twelve waves with fixed roles:
-//   * eight COMPUTE waves (two per SIMD: one wave alone issues a 16x16x32 MFMA every 32 clk, two interleave at 19 -- tools/dev/mfma_rate.hip),
+//   * eight COMPUTE waves (two per SIMD, so that one wave's split VALU work and LDS reads run beside the other's MFMAs),
 //     one 16-pixel fragment each (the same 8-fragment tile, the same packed weights, the same k-step order and MFMA pairing as the
 //     generic variant: bit-identical results);
 //   * four LOADER waves that do nothing but LDS-DMA: chunk k + 1 lands in the second stage buffer while chunk k multiplies, and since the

@@ -64,9 +64,15 @@ class CameraCreator:
         self.algorithm_name = algorithm
         self.conf_thresh = conf_thresh
         self.pitch = pitch if pitch is not None else PITCH_POINTS
-        for i, name in INTERSECTON_TO_PITCH_POINTS.items():      # the device template is fixed: refuse another pitch
+        # A pitch dict that differs from the template is REFUSED, on purpose.  The reference reads `self.pitch` in some places
+        # (prediction.py:149, 200, 240, 381: the calibration views of opencv_calibration(_multiplane) and original_voter) and the
+        # module-level PITCH_POINTS in others (:465 get_matched_points -> every refine_camera / projection_rmse, :505, :534, :582: the
+        # homography camera and all of voter's subset cameras), so with another pitch its voters calibrate against one template and
+        # refine / score against another.  make_submit.py:45 passes PITCH_POINTS itself; reproducing that inconsistency would serve nobody.
+        for i, name in INTERSECTON_TO_PITCH_POINTS.items():
             if name in self.pitch and not np.allclose(self.pitch[name], PITCH_POINTS[name], atol=1e-9):
-                raise ValueError(f'pitch point {name} differs from the built-in 105x68 m template')
+                raise ValueError(f'pitch point {name} differs from the built-in 105x68 m template (the reference itself mixes '
+                                 'self.pitch with its module-level PITCH_POINTS: see the comment above)')
         self.img_size = tuple(img_size)
         self.lines_data = self._line_keypoints(lines_file) if lines_file is not None else {}
         # defaults of the kwargs make_submit.py:45-50 passes

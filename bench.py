@@ -18,6 +18,10 @@ every backbone tensor (stem, Bottlenecks, transitions, every BasicBlock of every
 through the upsampled branch channels, on top of the random network's noise.  The heatmaps come out peaked on known cells for the
 visible keypoints -- what a trained network hands to HRNetPredictionTransform / CameraCreator -- and every arithmetic error of a
 fast engine inside the backbone acts on the decoded keypoints.  Every convolution runs at its full size on dense data.
+Four distinct batches of such frames (--frame-sets) are resident in HBM and cycled step by step, so the steps solve different keypoint
+sets (`config.frame_sets.by_set`: solve time and cameras found per batch -- one of the four holds a frame whose fits crawl to the
+reference's 20000 iterations, the others solve in under 2 ms); with the driver's --warmup 5 --steps 20 the last step is batch 0, the
+batch rounds 2-5 ran every step, so `drain_ms` and the parity fields stay comparable.
 
 Engine.  The benchmarked engine is `fp16x3` (default, and load_model's default): fp32 tensors and fp32 accumulation, every product
 formed on the 16-bit matrix pipe from split operands (x = hi + lo, two fp16; hi.hi + hi.lo + lo.hi: the dropped term is ~2^-22 of a
@@ -454,6 +458,9 @@ def main():
                          "lines through the stamped keypoints (synth.line_deep_state_dict), joined at get_line_data's own prob_thre 0.2: line points "
                          "consistent with the frame, as a trained line network gives; 'random' = the raw random-init line network at the export "
                          "CLI's prob_thre 0 (rounds 2-5): 28 garbage line points per frame, a stress case for the solve (most fits crawl)")
+    ap.add_argument('--frame-sets', type=int, default=0,
+                    help='distinct batches of synthetic frames resident in HBM, cycled step by step (default: 4 at 540p, 1 at 1080p): the '
+                         'steps then solve different keypoint sets -- the solve time and the cameras found are not one sample')
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
@@ -515,11 +522,18 @@ def main():
             lnets.append(ln)
     HW = (540, 960) if args.size == '540p' else (1080, 1920)
     n_distinct = B if args.size == '540p' else min(B, 16)        # 1080p: 16 distinct frames, repeated (host memory / start-up time)
-    frames_cpu, expect = sncal_amd.synth.stamped_frames(n_distinct, seed=1000 + rank, size=HW)     # synthetic frames, then resident in HBM
-    frames_cpu = torch.from_numpy(frames_cpu)
+    # several distinct batches, all resident in HBM before the timed region, cycled step by step (set 0 = the frames of rounds 2-5)
+    n_sets = args.frame_sets if args.frame_sets > 0 else (4 if args.size == '540p' else 1)
     reps = (B + n_distinct - 1) // n_distinct
-    x = frames_cpu.to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
-    expect = np.tile(expect, (reps, 1, 1))[:B]
+    F_sets, X_sets, E_sets = [], [], []
+    for si in range(n_sets):
+        f_cpu, e = sncal_amd.synth.stamped_frames(n_distinct, seed=1000 + rank + 7919 * si, size=HW)     # synthetic frames, then resident in HBM
+        f_cpu = torch.from_numpy(f_cpu)
+        F_sets.append(f_cpu)
+        X_sets.append(f_cpu.to(dev).repeat(reps, 1, 1, 1)[:B].contiguous())
+        E_sets.append(np.tile(e, (reps, 1, 1))[:B])
+    frames_cpu, x, expect = F_sets[0], X_sets[0], E_sets[0]
+    cur = {'n': 0, 'last': 0}
     if args.dtype == 'fp8':
         for n in nets:
             n.calibrate_fp8(x[:4])
@@ -529,7 +543,8 @@ def main():
              for i in range(L)]
     lane_streams = [None] if L == 1 else [torch.cuda.Stream(device=dev) for _ in range(L)]
     bl = B // L
-    xs = [x[i * bl:(i + 1) * bl] for i in range(L)]
+    XS_sets = [[X[i * bl:(i + 1) * bl] for i in range(L)] for X in X_sets]
+    xs = XS_sets[0]
     last = {}
     diag = os.environ.get('SNCAL_BENCH_DIAG')
     diag_nosolve = diag == 'nosolve'
@@ -538,6 +553,10 @@ def main():
     step_marks = []                                      # one event per step at the head of its forward: the steady-state step time
 
     def step():
+        si = cur['n'] % n_sets                            # this step's batch of frames
+        cur['n'] += 1
+        cur['last'] = si
+        xs = XS_sets[si]
         if L == 1 and not diag_nosolve:
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
@@ -595,6 +614,8 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    # everything below describes the LAST step's batch of frames (its keypoints and records are what `last` holds)
+    frames_cpu, x, expect, xs = F_sets[cur['last']], X_sets[cur['last']], E_sets[cur['last']], XS_sets[cur['last']]
     # steady state: head of step 0's forward to head of the last step's forward; what is left of dt is the pipeline's drain -- the
     # solve of the LAST batch has nothing to overlap with inside a timed region that must end with every solve complete
     steady_ms = step_marks[0].elapsed_time(step_marks[-1]) / (len(step_marks) - 1) if len(step_marks) > 1 else None
@@ -625,6 +646,19 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     solve_ms = ev[0].elapsed_time(ev[1]) / 3
+    # ... and of every batch of frames the steps cycled through (one forward + one synchronous solve each, outside the timed region): the
+    # solve's latency is set by its slowest Levenberg-Marquardt fit, which differs from batch to batch
+    by_set = None
+    if rank == 0 and L == 1 and n_sets > 1 and not c4:
+        by_set = []
+        for si in range(n_sets):
+            _, kps = nets[0].forward(XS_sets[si][0], want_heat=False, decode_size=(540, 960))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rs = cc.solve_device(kps)
+            e1.record()
+            torch.cuda.synchronize()
+            by_set.append({'solve_ms': round(e0.elapsed_time(e1), 1), 'cameras_found': sum(1 for r in cc.records(rs) if r.status != 0)})
     # what the solves cost the step: the same K steps of network + decode alone (no solve, no gather), outside the timed region
     solver_note = None
     if rank == 0 and L == 1 and not diag:
@@ -706,6 +740,8 @@ def main():
             'config': {'workload': wl, 'frames_per_gpu': B, 'lanes': L,
                        'parallelism': f'frames sharded over {world} GPU(s), records stay on the rank, ONE all_gather of all {args.steps} steps\' records closes the timed region' if world > 1 else 'single GPU',
                        'solve_ms_per_batch': round(solve_ms, 3), 'cameras_found': f'{n_cam}/{B}', 'solver': solver_note,
+                       'frame_sets': {'n': n_sets, 'what': 'distinct batches of frames resident in HBM, cycled step by step; the parity / hit-rate / cameras_found fields describe the last step\'s batch',
+                                      'by_set': by_set},
                        'decoded_within_8px_of_stamp': round(hit, 4), 'visible_keypoint_conf_median': round(float(np.median(conf_vis)), 4),
                        'network_tflops_reference_formulation': round(world * B * args.steps / dt * flop_frame / 1e12, 1),
                        'kernel_time_share_last_warmup_step': {p['kernel']: round(p['ms'] / total_ms, 4) for p in sorted(warm, key=lambda q: -q['ms'])[:8]}},

@@ -77,3 +77,36 @@ def test_cameras_follow_submission_order(sncal, cuda):
     for a, b in zip(cams0, ref0):
         if a is not None:
             assert a.rmse == b.rmse and np.array_equal(a.position, b.position)
+
+
+def test_line_branch_records_equal_the_synchronous_pieces(sncal, cuda):
+    """C4's data flow through the pipeline (keypoint net + line net + two-peak decode + device line join + solve WITH line points on the
+    pooled CU-masked streams) against the same pieces called one by one: the records must be the bytes of
+    CameraCreator.solve_device(kpts, line_points) on the pipeline's own keypoints and line points."""
+    import bench
+    from sncal_amd.lines import lines_to_points_device
+    B = 4
+    knet = sncal.HRNetHeatmap('hrnet_w48', dtype='fp16x3', device=cuda)
+    knet.load_state_dict(sncal.synth.peaked_state_dict(bench.seeded_weights('hrnet_w48', seed=1), deep=True))
+    lnet = sncal.HRNetHeatmap('line_hrnet_w48', dtype='fp16x3', device=cuda)
+    lnet.load_state_dict(sncal.synth.line_deep_state_dict(bench.seeded_weights('line_hrnet_w48', seed=2)))
+    cc = sncal.CameraCreator(sncal.PITCH_POINTS, **KW)
+    frames, _ = sncal.synth.stamped_frames(3 * B, seed=1000, size=(540, 960))
+    x = torch.from_numpy(frames).to(cuda)
+    for thre in (0.2, 0.0):                                   # the designed join, and the export CLI's prob_thre 0 (every line pair "intersects")
+        pipe = sncal.CalibrationPipeline(knet, cc, decode_size=(540, 960), line_net=lnet, line_prob_thre=thre)
+        with pipe.stream():
+            outs = [pipe.submit(x[b * B:(b + 1) * B]) for b in range(3)]
+            pipe.join()
+        torch.cuda.synchronize()
+        n_lp = 0
+        for b, (kpts, rec) in enumerate(outs):
+            xb = x[b * B:(b + 1) * B]
+            _, k_ref = knet.forward(xb, want_heat=False, decode_size=(540, 960))
+            heat, _ = lnet.forward(xb, want_heat=True)
+            lp = lines_to_points_device(sncal.EHMPredictionTransform.mask_heat_points_gauss(heat, sigma=3.0), scale=4.0, prob_thre=thre)
+            ref = cc.solve_device(k_ref, lp)
+            torch.cuda.synchronize()
+            assert torch.equal(kpts, k_ref) and torch.equal(rec, ref), (thre, b)
+            n_lp += int((lp[..., 2] > 0.5).sum())
+        assert n_lp > 0

@@ -291,14 +291,22 @@ def lanes_leg(sncal_amd, cfg_name, sd, x, cc, dev, dtype, lanes=2, steps=5, warm
     for _ in range(warm):
         step()
     fence()
+    marks = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        with torch.cuda.stream(streams[0]):
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         step()
     fence()
     dt = time.perf_counter() - t0
+    steady = marks[0].elapsed_time(marks[-1]) / (len(marks) - 1) if len(marks) > 1 else None
     del pipes, nets
     return {'value': round(steps * B / dt, 2), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 2), 'lanes': lanes, 'frames': int(B),
             'steps': steps, 'dtype': dtype,
+            'steady_state_ms_per_step': round(steady, 3) if steady else None,
+            'steady_state_frames_per_s': round(B / steady * 1e3, 1) if steady else None,
+            'drain_ms': round(dt * 1e3 - steady * steps, 1) if steady else None,
             'what': f'the same step with the {B} frames as {lanes} independent sub-batches on their own streams (bench.py --lanes {lanes}); '
                     'not the driver line: per-kernel durations of a shared GPU do not make a roofline'}
 
@@ -788,7 +796,7 @@ def main():
                                                                    steps=args.steps if args.size == '540p' else 3)
             out[other] = out_other
             if args.size == '540p' and not c4 and L == 1 and args.dtype != 'fp8':
-                out['lanes2'] = lanes_leg(sncal_amd, cfg_name, sd, x, cc, dev, args.dtype)
+                out['lanes2'] = lanes_leg(sncal_amd, cfg_name, sd, x, cc, dev, args.dtype, steps=args.steps)      # (the headline's step count: the same drain share)
         if world == 1 and not args.no_parity and args.size == '540p' and not c4 and args.dtype != 'fp8':
             try:
                 out['input_stage'] = input_stage_leg(sncal_amd, nets[0], cc, dev)

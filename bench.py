@@ -401,7 +401,7 @@ def parity_leg(sncal_amd, cfg_name, sd, x, cc, kp_fast, rec_fast, dev, steps=3, 
 
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec under torch.distributed.run with one rank per
-    GPU (frames sharded over the GPUs of one node, one RCCL all_gather per step), so that the command the driver
+    GPU (frames sharded over the GPUs of one node, ONE RCCL all_gather after the last step), so that the command the driver
     runs verbatim measures N GPUs.  Fails loudly when fewer than N devices are visible."""
     if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
         return
